@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name)))
+
+
+def checksum(x):
+    """Same three-moment checksum tests/golden/make_golden.py stores for inputs and weights."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    return np.array([x.sum(), np.abs(x).sum(), (x * np.cos(np.arange(x.size) * 0.37)).sum()])
+
+
+def cosine_rows(a, b):
+    a = np.asarray(a, np.float64).reshape(a.shape[0], -1)
+    b = np.asarray(b, np.float64).reshape(b.shape[0], -1)
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1) + 1e-30)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture(scope="session")
+def full_state():
+    """Seeded full-size CACO state dict (210 M parameters, ~10 s to hash)."""
+    from cacophony_amd import config as C
+    from cacophony_amd import synth
+    return synth.make_caco_state(C.default_audio_config(), C.default_text_config(), C.default_caco_config())
+
+
+@pytest.fixture(scope="session")
+def tiny_state():
+    from cacophony_amd import config as C
+    from cacophony_amd import synth
+    a, t, cc = C.tiny_configs(2)
+    return synth.make_caco_state(a, t, cc)

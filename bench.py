@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-text pairs/sec embedded + scored on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one synthetic batch that is already resident in HBM:
+  wav fp32 [256, 160000] -> fused log-mel patches (bf16) -> AudioMAE-ViT encoder + pooler -> L2 norm
+  ids/mask int64 [256, 32] -> causal RoBERTa encoder + pooler + projection -> L2 norm
+  [N > 1: ONE RCCL all-gather of both embedding banks]  -> similarity row block [256, N*256]
+Per-GPU work is fixed as N grows (weak scaling); value = N * 256 * steps / wall, wall = max over ranks
+between two barrier + synchronize brackets.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line; it also carries
+  roofline     : the dominant kernel (the 768 -> 3072 SiLU bf16 MFMA GEMM of the audio MLP), achieved
+                 algorithmic TFLOP/s from its average launch duration measured with HIP events recorded
+                 inside the library on the launch stream, vs the 2.5 PFLOP/s dense bf16 MFMA peak;
+  stages       : the same per-launch-group timing for every stage (mel: HBM GB/s vs 8 TB/s);
+  cpu_baseline : the CPU oracle (torch CPU ops, "port" of the reference's src/caco_torch path) timed on
+                 this box's host cores on a bounded sample (batch 4), rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+B_PER_GPU = 256
+N_SAMPLES = 160000
+SEQ = 500          # 496 valid patches padded to patches_seq_len = 500 (src/eval/eval_caco_torch.py:573)
+TEXT_LEN = 32
+H, I, P = 768, 3072, 256
+PEAK_BF16_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic FLOPs (2 * MACs) per launch group at batch 256; SURVEY.md section 8d
+def _flops(batch):
+    M, Mt = batch * SEQ, batch * TEXT_LEN
+    S_attn = 2 * 2 * SEQ * SEQ * H            # QK^T + PV per clip, all heads
+    T_attn = 2 * 2 * TEXT_LEN * TEXT_LEN * H
+    return {
+        "audio.patch_embed": 2 * M * P * H, "audio.gemm_qk": 2 * M * H * 2 * H, "audio.gemm_v": 2 * M * H * H,
+        "audio.attention": batch * S_attn, "audio.gemm_out": 2 * M * H * H, "audio.gemm_fc1": 2 * M * H * I,
+        "audio.gemm_fc2": 2 * M * I * H, "audio.pool_kv_gemm": 2 * M * H * 2 * H,
+        "text.gemm_qk": 2 * Mt * H * 2 * H, "text.gemm_v": 2 * Mt * H * H, "text.attention": batch * T_attn,
+        "text.gemm_out": 2 * Mt * H * H, "text.gemm_fc1": 2 * Mt * H * I, "text.gemm_fc2": 2 * Mt * I * H,
+        "text.pool_kv_gemm": 2 * Mt * H * 2 * H,
+    }
+
+
+def _bytes(batch):
+    M = batch * SEQ
+    return {
+        "mel.patches": batch * (N_SAMPLES * 4 + 496 * 256 * 2),      # fp32 samples in + bf16 patches out
+        "audio.ln": M * H * (4 + 2),                                  # fp32 residual in, bf16 operand out
+        "audio.pos_embed": M * H * 8,
+    }
+
+
+def _make_inputs(batch, rank, device):
+    from cacophony_amd import synth
+    base = synth.make_waveforms(16, N_SAMPLES, start=100 + 16 * rank)       # 16 distinct structured clips per rank
+    reps = (batch + 15) // 16
+    gains = (0.35 + 0.65 * (np.arange(reps) + 1) / reps).astype(np.float32)
+    wav = np.concatenate([base * g for g in gains], 0)[:batch]
+    ids, mask = synth.make_captions(batch, TEXT_LEN, 50265, start=batch * rank)
+    return (torch.from_numpy(wav).to(device), torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device))
+
+
+def _cpu_baseline(state):
+    """Oracle (torch CPU ops) on a bounded sample of the same workload: batch 4, full-size model."""
+    from cacophony_amd import config as Cfg
+    from cacophony_amd import synth
+    from oracle import caco_oracle as O
+    b = 4
+    threads = torch.get_num_threads()
+    ref = O.CacoOracle(state, Cfg.default_audio_config(), Cfg.default_text_config(), Cfg.default_caco_config(), backend="torch")
+    wav = synth.make_waveforms(b, N_SAMPLES, start=100)
+    ids, mask = synth.make_captions(b, TEXT_LEN)
+
+    def run():
+        with torch.no_grad():
+            ea, et = ref.encode_audio(wav, SEQ), ref.encode_text(ids, mask)
+            return O.similarity(ea, et)
+
+    run()
+    times = []
+    t_end = time.time() + 25.0
+    while len(times) < 5 and (len(times) < 2 or time.time() < t_end):
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(b / med, 3), "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"batch {b} x 10 s clips + {TEXT_LEN}-token captions, full 12+12-layer model, oracle torch-CPU backend, "
+                      f"median of {len(times)} runs ({med * 1e3:.0f} ms each)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from cacophony_amd import _lib, config as Cfg, synth
+    from cacophony_amd.dist import gather_embedding_banks
+    from cacophony_amd.model import create_caco_model, similarity
+
+    lib = _lib.load()
+    state = synth.make_caco_state(Cfg.default_audio_config(), Cfg.default_text_config(), Cfg.default_caco_config())
+    model = create_caco_model(device=device).load_state_dict(state)
+    wav, ids, mask = _make_inputs(B_PER_GPU, rank, device)
+    sim_out = torch.empty(B_PER_GPU, world * B_PER_GPU, dtype=torch.float32, device=device)
+
+    def step():
+        ea = model.encode_audio(wav, SEQ)
+        et = model.encode_text(ids, mask)
+        _, t_all = gather_embedding_banks(ea, et)
+        return similarity(ea, t_all, 1.0, out=sim_out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B_PER_GPU * args.steps / elapsed
+    finite = bool(torch.isfinite(sim_out).all().item())
+
+    # ---- per-launch-group timing with HIP events on the launch stream (separate, un-timed pass) -----------------
+    stages, roofline = {}, None
+    if rank == 0:
+        lib.caco_profile_enable(1)
+        for _ in range(max(1, args.profile_steps)):
+            step()
+        torch.cuda.synchronize()
+        buf = C.create_string_buffer(1 << 16)
+        lib.caco_profile_report(buf, len(buf))
+        lib.caco_profile_enable(0)
+        prof = json.loads(buf.value.decode())
+        fl, by = _flops(B_PER_GPU), _bytes(B_PER_GPU)
+        psteps = max(1, args.profile_steps)
+        for name, rec in sorted(prof.items()):
+            avg_ms = rec["ms"] / rec["n"]
+            ent = {"ms_per_step": round(rec["ms"] / psteps, 4), "launches_per_step": rec["n"] // psteps, "avg_launch_ms": round(avg_ms, 5)}
+            if name in fl:
+                tf = fl[name] / (avg_ms * 1e-3) / 1e12
+                ent.update(bound="mfma", achieved_tflops=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4))
+            elif name in by:
+                gbs = by[name] / (avg_ms * 1e-3) / 1e9
+                ent.update(bound="hbm", achieved_gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+            stages[name] = ent
+        dom = stages.get("audio.gemm_fc1")
+        if dom:
+            roofline = {"kernel": "gemm_bf16_kernel<EPI_BF16, SiLU> (audio MLP fc1: [128000,768] x [3072,768]^T)",
+                        "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dom["frac"], "traffic": None,
+                        "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = _cpu_baseline(state)
+
+    if rank == 0:
+        out = {
+            "metric": "audio-text pairs/sec embedded+scored, 10s@16kHz, batch 256, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] per GPU (batch=256 audio+text encoders + similarity GEMM, bf16 MFMA, "
+                                   "fp32 accumulate/residual/softmax/LayerNorm), sharded as configs[3] when n_gpus > 1 "
+                                   "(one RCCL all-gather of both [256,768] fp32 banks, local [256, N*256] row block)",
+                       "global_batch": world * B_PER_GPU, "clip": "10 s @ 16 kHz (160000 samples, 500 patches, 496 valid)",
+                       "caption_tokens": TEXT_LEN, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)",
+                       "gemm_tile": int(lib.caco_set_gemm_tile(0))},
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "outputs_finite": finite,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

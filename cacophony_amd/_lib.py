@@ -1,0 +1,108 @@
+"""ctypes binding of libcaco_hip.so (include/caco_hip.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X path (see
+INTEGRATION.md).  There is deliberately NO fallback: if the shared library is missing or a call
+fails, a RuntimeError / ValueError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List, Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcaco_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "caco_hip.h")
+
+CACO_OK = 0
+CACO_ERR_INVALID = -1
+DTYPE_F32 = 0
+DTYPE_BF16 = 1
+
+
+class CacoConfigC(C.Structure):
+    _fields_ = [
+        ("audio_hidden", C.c_int32), ("audio_layers", C.c_int32), ("audio_heads", C.c_int32),
+        ("audio_intermediate", C.c_int32), ("patch_size", C.c_int32), ("num_freq_patches", C.c_int32),
+        ("audio_ln_eps", C.c_float),
+        ("text_vocab", C.c_int32), ("text_hidden", C.c_int32), ("text_layers", C.c_int32), ("text_heads", C.c_int32),
+        ("text_intermediate", C.c_int32), ("text_max_pos", C.c_int32), ("text_type_vocab", C.c_int32),
+        ("text_ln_eps", C.c_float),
+        ("projection_size", C.c_int32), ("pool_heads", C.c_int32), ("logit_scale", C.c_float),
+        ("has_audio", C.c_int32), ("has_text", C.c_int32), ("mae_decoder_layers", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+_SIGNATURES = {
+    "caco_version": (C.c_char_p, []),
+    "caco_last_error": (C.c_char_p, []),
+    "caco_default_config": (None, [C.POINTER(CacoConfigC)]),
+    "caco_create": (C.c_int, [C.POINTER(CacoConfigC), C.POINTER(_vp)]),
+    "caco_destroy": (None, [_vp]),
+    "caco_load_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32]),
+    "caco_finalize_weights": (C.c_int, [_vp]),
+    "caco_set_logit_scale": (C.c_int, [_vp, _f32]),
+    "caco_get_logit_scale": (_f32, [_vp]),
+    "caco_mel_num_frames": (_i64, [_i64]),
+    "caco_mel_spectrogram": (C.c_int, [_vp, _i32, _i64, _f32, _f32, _vp, _vp]),
+    "caco_mel_patches": (C.c_int, [_vp, _i32, _i64, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "caco_audio_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "caco_text_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "caco_encode_audio": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "caco_similarity": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "caco_l2_normalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "caco_mae_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "caco_workspace_bytes": (_i64, [_vp]),
+    "caco_set_gemm_tile": (_i32, [_i32]),
+    "caco_profile_enable": (C.c_int, [_i32]),
+    "caco_profile_report": (_i64, [C.c_char_p, _i64]),
+    "caco_op_gemm_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "caco_attn_seq_pad": (_i32, [_i32]),
+    "caco_op_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_op_gemm_bf16_vt": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def declared_symbols(header: str = HEADER_PATH) -> List[str]:
+    """Every function name include/caco_hip.h declares."""
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(caco_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    """Load the library and bind argument types.  Raises if it is absent: no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (build it with `python -m cacophony_amd.build`); "
+            "cacophony_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().caco_last_error().decode("utf-8", "replace")
+
+
+def check(status: int, what: str = "") -> None:
+    if status == CACO_OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if status == CACO_ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"{msg} (status {status})")

@@ -1,0 +1,749 @@
+// C-ABI layer of libcaco_hip.so (include/caco_hip.h): model lifetime, weight ingestion by reference
+// state-dict key, workspace arena, and the forward orchestration that strings the kernels of
+// gemm.hip / attention.hip / norm.hip / pool.hip / mel.hip together on the caller's stream.
+// No exception leaves this file; every entry point returns a status and records a message.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace caco {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return CACO_OK;
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return CACO_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optional per-stage timing: HIP event pairs recorded on the caller's stream around each launch group
+// ------------------------------------------------------------------------------------------------
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  hipStream_t st; bool on;
+  ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof_on) {
+    if (on) { ProfRec r{name, prof_event(), prof_event()}; (void)hipEventRecord(r.a, st); g_prof_recs.push_back(r); }
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(g_prof_recs.back().b, st); }
+};
+#define CACO_STAGE(name, expr)            \
+  do {                                    \
+    int _rc;                              \
+    { caco::ProfScope _ps(name, st); _rc = (expr); } \
+    if (_rc) return _rc;                  \
+  } while (0)
+
+namespace {
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct Lin {          // bf16 weight [out, in] + fp32 bias
+  bf16_t* w = nullptr;
+  float* b = nullptr;
+  int out = 0, in = 0;
+};
+struct LNp {
+  float* g = nullptr;
+  float* b = nullptr;
+};
+struct AudioLayer {   // AudioEncoderLayer, audio_models/mae.py:64-99
+  LNp ln1, ln2;
+  Lin qk, v, o, fc1, fc2;
+};
+struct AudioStack {   // AudioEncoder / AudioDecoder trunk
+  Lin input_proj;
+  float* freq_table = nullptr;   // [num_freq, H]
+  float* restore_patch = nullptr;
+  std::vector<AudioLayer> layers;
+  LNp norm;
+  Lin output_proj;               // decoder only
+};
+struct TextLayer {    // RobertaLayer, text_models/roberta.py:181-215
+  Lin qk, v, attn_out, inter, out;
+  LNp ln_attn, ln_out;
+};
+
+}  // namespace
+}  // namespace caco
+
+using namespace caco;
+
+struct caco_model {
+  caco_config cfg;
+  bool finalized = false;
+  std::map<std::string, HostTensor> pending;
+  std::vector<void*> owned;          // every device allocation holding weights
+  // audio tower + pooler (caco.py:100-107)
+  AudioStack enc, dec;
+  float* pool_query = nullptr;
+  Lin pool_kv;
+  float *pool_out_w = nullptr, *pool_out_b = nullptr;   // fp32 [proj, H]
+  // text tower (caco.py:110-113)
+  float *word = nullptr, *pos = nullptr, *type0 = nullptr;
+  LNp emb_ln;
+  std::vector<TextLayer> tlayers;
+  float* tpool_query = nullptr;
+  Lin tpool_kv;
+  float *text_proj_w = nullptr, *text_proj_b = nullptr;
+  float logit_scale = 0.f;
+  // workspace arena
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+namespace caco {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+  caco_model* m;
+  std::string err;
+
+  const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = m->pending.find(key);
+    if (it == m->pending.end()) {
+      if (err.empty()) err = "missing tensor '" + key + "'";
+      return nullptr;
+    }
+    std::vector<int64_t> want(shape);
+    if (it->second.shape != want) {
+      if (err.empty()) {
+        err = "tensor '" + key + "' has shape [";
+        for (auto d : it->second.shape) err += std::to_string(d) + ",";
+        err += "], expected [";
+        for (auto d : want) err += std::to_string(d) + ",";
+        err += "]";
+      }
+      return nullptr;
+    }
+    return &it->second;
+  }
+
+  float* upload_f32(const float* src, size_t n) {
+    void* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) { if (err.empty()) err = "hipMalloc failed"; return nullptr; }
+    m->owned.push_back(d);
+    if (hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess && err.empty()) err = "hipMemcpy failed";
+    return reinterpret_cast<float*>(d);
+  }
+  bf16_t* upload_bf16(const float* src, size_t n) {
+    std::vector<uint16_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(src[i]);
+    void* d = nullptr;
+    if (hipMalloc(&d, n * 2) != hipSuccess) { if (err.empty()) err = "hipMalloc failed"; return nullptr; }
+    m->owned.push_back(d);
+    if (hipMemcpy(d, tmp.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess && err.empty()) err = "hipMemcpy failed";
+    return reinterpret_cast<bf16_t*>(d);
+  }
+
+  float* vec(const std::string& key, int64_t n) {
+    const HostTensor* t = get(key, {n});
+    return t ? upload_f32(t->data.data(), (size_t)n) : nullptr;
+  }
+  float* mat_f32(const std::string& key, int64_t r, int64_t c) {
+    const HostTensor* t = get(key, {r, c});
+    return t ? upload_f32(t->data.data(), (size_t)(r * c)) : nullptr;
+  }
+  LNp ln(const std::string& p, int h) {
+    LNp o;
+    o.g = vec(p + ".weight", h);
+    o.b = vec(p + ".bias", h);
+    return o;
+  }
+  // Linear from rows [r0, r0+rows) of a [total, in] weight and its bias
+  Lin lin_rows(const std::string& wkey, const std::string& bkey, int total, int in, int r0, int rows) {
+    Lin o;
+    const HostTensor* w = get(wkey, {total, in});
+    const HostTensor* b = get(bkey, {total});
+    if (!w || !b) return o;
+    o.w = upload_bf16(w->data.data() + (size_t)r0 * in, (size_t)rows * in);
+    o.b = upload_f32(b->data.data() + r0, (size_t)rows);
+    o.out = rows;
+    o.in = in;
+    return o;
+  }
+  Lin lin(const std::string& p, int out, int in) { return lin_rows(p + ".weight", p + ".bias", out, in, 0, out); }
+  // Linear whose rows are the concatenation of several [rows_i, in] Linears (fused projections)
+  Lin lin_cat(const std::vector<std::string>& ps, int rows_each, int in) {
+    Lin o;
+    std::vector<float> w, b;
+    for (auto& p : ps) {
+      const HostTensor* tw = get(p + ".weight", {rows_each, in});
+      const HostTensor* tb = get(p + ".bias", {rows_each});
+      if (!tw || !tb) return o;
+      w.insert(w.end(), tw->data.begin(), tw->data.end());
+      b.insert(b.end(), tb->data.begin(), tb->data.end());
+    }
+    o.w = upload_bf16(w.data(), w.size());
+    o.b = upload_f32(b.data(), b.size());
+    o.out = rows_each * (int)ps.size();
+    o.in = in;
+    return o;
+  }
+
+  void audio_layers(AudioStack& s, const std::string& prefix, int nlayers, int H, int I) {
+    for (int n = 0; n < nlayers; ++n) {
+      const std::string p = prefix + ".layers." + std::to_string(n);
+      AudioLayer L;
+      L.ln1 = ln(p + ".norm1", H);
+      // packed in_proj rows [Wq; Wk; Wv] (torch.nn.MultiheadAttention): Q|K as one GEMM, V as the transposed-store GEMM
+      L.qk = lin_rows(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias", 3 * H, H, 0, 2 * H);
+      L.v = lin_rows(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias", 3 * H, H, 2 * H, H);
+      L.o = lin(p + ".attn.out_proj", H, H);
+      L.ln2 = ln(p + ".norm2", H);
+      L.fc1 = lin(p + ".mlp.fc1", I, H);
+      L.fc2 = lin(p + ".mlp.fc2", H, I);
+      s.layers.push_back(L);
+    }
+  }
+};
+
+int build_weights(caco_model* m) {
+  const caco_config& c = m->cfg;
+  Builder B{m, ""};
+  const bool mae_names = m->pending.count("encoder.input_proj.weight") > 0;
+  if (c.has_audio) {
+    const std::string ap = mae_names ? "encoder" : "audio_module";
+    const int H = c.audio_hidden;
+    m->enc.input_proj = B.lin(ap + ".input_proj", H, c.patch_size);
+    m->enc.freq_table = B.mat_f32(ap + ".freq_positional_embedding", c.num_freq_patches, H);
+    B.audio_layers(m->enc, ap, c.audio_layers, H, c.audio_intermediate);
+    m->enc.norm = B.ln(ap + ".norm", H);
+    if (!mae_names) {
+      m->pool_query = B.vec("audio_attention_pool.query", H);
+      m->pool_kv = B.lin("audio_attention_pool.kv_proj", 2 * H, H);
+      m->pool_out_w = B.mat_f32("audio_attention_pool.out_proj.weight", c.projection_size, H);
+      m->pool_out_b = B.vec("audio_attention_pool.out_proj.bias", c.projection_size);
+    }
+    if (c.mae_decoder_layers > 0) {
+      m->dec.input_proj = B.lin("decoder.input_proj", H, H);
+      m->dec.freq_table = B.mat_f32("decoder.freq_positional_embedding", c.num_freq_patches, H);
+      m->dec.restore_patch = B.vec("decoder.restore_patch", H);
+      B.audio_layers(m->dec, "decoder", c.mae_decoder_layers, H, c.audio_intermediate);
+      m->dec.norm = B.ln("decoder.norm", H);
+      m->dec.output_proj = B.lin("decoder.output_proj", c.patch_size, H);
+    }
+  }
+  if (c.has_text) {
+    const int H = c.text_hidden;
+    const std::string e = "text_module.embeddings";
+    m->word = B.mat_f32(e + ".word_embeddings.weight", c.text_vocab, H);
+    m->pos = B.mat_f32(e + ".position_embeddings.weight", c.text_max_pos, H);
+    m->type0 = B.mat_f32(e + ".token_type_embeddings.weight", c.text_type_vocab, H);
+    m->emb_ln = B.ln(e + ".LayerNorm", H);
+    for (int n = 0; n < c.text_layers; ++n) {
+      const std::string p = "text_module.encoder.layers." + std::to_string(n);
+      TextLayer L;
+      L.qk = B.lin_cat({p + ".attention.self.query", p + ".attention.self.key"}, H, H);
+      L.v = B.lin(p + ".attention.self.value", H, H);
+      L.attn_out = B.lin(p + ".attention.output.dense", H, H);
+      L.ln_attn = B.ln(p + ".attention.output.LayerNorm", H);
+      L.inter = B.lin(p + ".intermediate.dense", c.text_intermediate, H);
+      L.out = B.lin(p + ".output.dense", H, c.text_intermediate);
+      L.ln_out = B.ln(p + ".output.LayerNorm", H);
+      m->tlayers.push_back(L);
+    }
+    const HostTensor* q = B.get("text_module.pooler.attention_pool_query", {1, H});
+    if (q) m->tpool_query = B.upload_f32(q->data.data(), (size_t)H);
+    m->tpool_kv = B.lin_cat({"text_module.pooler.key_proj", "text_module.pooler.value_proj"}, H, H);
+    m->text_proj_w = B.mat_f32("text_proj.weight", c.projection_size, H);
+    m->text_proj_b = B.vec("text_proj.bias", c.projection_size);
+  }
+  auto ls = m->pending.find("logit_scale");
+  if (ls != m->pending.end() && ls->second.data.size() == 1) m->logit_scale = ls->second.data[0];
+  if (!B.err.empty()) {
+    set_error("caco_finalize_weights: %s", B.err.c_str());
+    return CACO_ERR_INVALID;
+  }
+  return CACO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+  caco_model* m;
+  size_t off = 0;
+  explicit Arena(caco_model* mm) : m(mm) {}
+  size_t reserve(size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+  int commit(hipStream_t st) {
+    if (off <= m->ws_bytes) return CACO_OK;
+    CACO_HIP(hipStreamSynchronize(st));       // earlier work may still be using the old arena
+    if (m->ws) CACO_HIP(hipFree(m->ws));
+    m->ws = nullptr;
+    m->ws_bytes = 0;
+    CACO_HIP(hipMalloc(reinterpret_cast<void**>(&m->ws), off));
+    m->ws_bytes = off;
+    return CACO_OK;
+  }
+  template <typename T>
+  T* at(size_t o) const { return reinterpret_cast<T*>(m->ws + o); }
+};
+
+int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st) {
+  GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, L.out, 0, 0};
+  return gemm_bf16(g, EPI_BF16, act, st);
+}
+int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st) {
+  GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out, 0, 0};
+  return gemm_bf16(g, EPI_F32, ACT_NONE, st);
+}
+int linear_vt(const Lin& L, const bf16_t* a, int batch, int seq, bf16_t* vt, hipStream_t st) {
+  GemmArgs g{a, L.w, L.b, nullptr, vt, (int64_t)batch * seq, L.out, L.in, L.out, seq, attn_seq_pad(seq)};
+  return gemm_bf16(g, EPI_VT, ACT_NONE, st);
+}
+
+#define CACO_TRY(expr)       \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc) return _rc;     \
+  } while (0)
+
+struct AudioWs {
+  size_t x, h, qk, vt, o, a;
+  void plan(Arena& A, int64_t M, int batch, int seq, int H, int I) {
+    x = A.reserve((size_t)M * H * 4);
+    h = A.reserve((size_t)M * H * 2);
+    qk = A.reserve((size_t)M * 2 * H * 2);
+    vt = A.reserve((size_t)batch * H * attn_seq_pad(seq) * 2);
+    o = A.reserve((size_t)M * H * 2);
+    a = A.reserve((size_t)M * I * 2);
+  }
+};
+
+// 12 x AudioEncoderLayer.forward (mae.py:80-99) on the fp32 residual stream x[M, H]
+int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const Arena& A, const AudioWs& w,
+                     const float* mask, int batch, int seq, int heads, float eps, hipStream_t st) {
+  const int H = m->cfg.audio_hidden;
+  const int64_t M = (int64_t)batch * seq;
+  float* x = A.at<float>(w.x);
+  bf16_t* h = A.at<bf16_t>(w.h);
+  bf16_t* qk = A.at<bf16_t>(w.qk);
+  bf16_t* vt = A.at<bf16_t>(w.vt);
+  bf16_t* o = A.at<bf16_t>(w.o);
+  bf16_t* a = A.at<bf16_t>(w.a);
+  // pad columns of V^T are multiplied by P = 0; they only have to be finite
+  CACO_HIP(hipMemsetAsync(vt, 0, (size_t)batch * H * attn_seq_pad(seq) * 2, st));
+  for (const AudioLayer& L : layers) {
+    CACO_STAGE("audio.ln", layernorm(x, L.ln1.g, L.ln1.b, M, H, eps, nullptr, h, st));
+    CACO_STAGE("audio.gemm_qk", linear_bf16(L.qk, h, M, ACT_NONE, qk, st));
+    CACO_STAGE("audio.gemm_v", linear_vt(L.v, h, batch, seq, vt, st));
+    CACO_STAGE("audio.attention", attention(qk, vt, mask, batch, seq, heads, H / heads, 0, o, st));
+    CACO_STAGE("audio.gemm_out", linear_f32(L.o, o, M, x, x, st));
+    CACO_STAGE("audio.ln", layernorm(x, L.ln2.g, L.ln2.b, M, H, eps, nullptr, h, st));
+    CACO_STAGE("audio.gemm_fc1", linear_bf16(L.fc1, h, M, ACT_SILU, a, st));
+    CACO_STAGE("audio.gemm_fc2", linear_f32(L.fc2, a, M, x, x, st));
+  }
+  return CACO_OK;
+}
+
+int check_audio_shapes(const caco_model* m, int batch, int seq) {
+  CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_REQUIRE(m->cfg.has_audio, "model was created without the audio tower");
+  CACO_REQUIRE(batch > 0 && seq > 0, "bad audio shape B=%d S=%d", batch, seq);
+  const int hd = m->cfg.audio_hidden / m->cfg.audio_heads;
+  CACO_REQUIRE(hd == 96 || hd == 64, "audio head_dim %d unsupported", hd);
+  return CACO_OK;
+}
+
+// patches (f32 | bf16) -> bf16 [M, P] operand, casting into scratch if needed
+int patches_as_bf16(const void* patches, int dtype, int64_t n, bf16_t* scratch, const bf16_t** out, hipStream_t st) {
+  if (dtype == CACO_DTYPE_BF16) {
+    *out = reinterpret_cast<const bf16_t*>(patches);
+    return CACO_OK;
+  }
+  CACO_REQUIRE(dtype == CACO_DTYPE_F32, "patch dtype %d unknown", dtype);
+  CACO_TRY(cast_f32_to_bf16(reinterpret_cast<const float*>(patches), scratch, n, st));
+  *out = scratch;
+  return CACO_OK;
+}
+
+}  // namespace
+}  // namespace caco
+
+// ================================================================================================
+// extern "C" surface
+// ================================================================================================
+extern "C" {
+
+const char* caco_version(void) { return "cacophony_amd 0.1 (gfx950)"; }
+const char* caco_last_error(void) { return caco::g_err; }
+
+void caco_default_config(caco_config* c) {
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->audio_hidden = 768; c->audio_layers = 12; c->audio_heads = 8; c->audio_intermediate = 3072;
+  c->patch_size = 256; c->num_freq_patches = 8; c->audio_ln_eps = 1e-5f;
+  c->text_vocab = 50265; c->text_hidden = 768; c->text_layers = 12; c->text_heads = 12; c->text_intermediate = 3072;
+  c->text_max_pos = 514; c->text_type_vocab = 1; c->text_ln_eps = 1e-5f;
+  c->projection_size = 768; c->pool_heads = 2; c->logit_scale = 2.6592f;
+  c->has_audio = 1; c->has_text = 1; c->mae_decoder_layers = 0;
+}
+
+int caco_create(const caco_config* cfg, caco_model** out) {
+  CACO_REQUIRE(cfg && out, "caco_create: null argument");
+  CACO_REQUIRE(cfg->has_audio || cfg->has_text, "caco_create: model needs at least one tower");
+  if (cfg->has_audio) {
+    CACO_REQUIRE(cfg->audio_hidden % 128 == 0 && cfg->audio_intermediate % 128 == 0 && cfg->patch_size % 128 == 0,
+                 "caco_create: audio hidden/intermediate/patch sizes must be multiples of 128");
+    CACO_REQUIRE(cfg->audio_heads > 0 && cfg->audio_hidden % cfg->audio_heads == 0, "caco_create: bad audio head count");
+    CACO_REQUIRE(cfg->pool_heads > 0 && cfg->audio_hidden % cfg->pool_heads == 0, "caco_create: bad pool head count");
+    CACO_REQUIRE(cfg->projection_size % 8 == 0, "caco_create: projection_size must be a multiple of 8");
+  }
+  if (cfg->has_text) {
+    CACO_REQUIRE(cfg->text_hidden % 128 == 0 && cfg->text_intermediate % 128 == 0, "caco_create: text sizes must be multiples of 128");
+    CACO_REQUIRE(cfg->text_heads > 0 && cfg->text_hidden / cfg->text_heads == 64 && cfg->text_hidden % cfg->text_heads == 0,
+                 "caco_create: text head_dim must be 64");
+  }
+  int dev = 0;
+  CACO_HIP(hipGetDevice(&dev));
+  caco_model* m = new (std::nothrow) caco_model();
+  CACO_REQUIRE(m, "caco_create: out of host memory");
+  m->cfg = *cfg;
+  m->logit_scale = cfg->logit_scale;
+  *out = m;
+  return CACO_OK;
+}
+
+void caco_destroy(caco_model* m) {
+  if (!m) return;
+  for (void* p : m->owned) (void)hipFree(p);
+  if (m->ws) (void)hipFree(m->ws);
+  delete m;
+}
+
+int caco_load_tensor(caco_model* m, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+  CACO_REQUIRE(m && name && host && (shape || ndim == 0) && ndim >= 0 && ndim <= 4, "caco_load_tensor: bad arguments");
+  if (m->finalized) {
+    set_error("caco_load_tensor: weights already finalized");
+    return CACO_ERR_STATE;
+  }
+  const std::string key(name);
+  if (key.rfind("decoder_module.", 0) == 0) return CACO_OK;   // caption decoder: out of scope, ignored
+  static const char* known[] = {"audio_module.", "audio_attention_pool.", "text_module.", "text_proj.", "logit_scale",
+                                "encoder.", "decoder."};
+  bool ok = false;
+  for (const char* k : known) ok = ok || key.rfind(k, 0) == 0;
+  CACO_REQUIRE(ok, "caco_load_tensor: unknown state-dict key '%s'", name);
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    CACO_REQUIRE(shape[i] > 0, "caco_load_tensor: non-positive dimension in '%s'", name);
+    t.shape.push_back(shape[i]);
+    n *= shape[i];
+  }
+  t.data.assign(host, host + n);
+  m->pending[key] = std::move(t);
+  return CACO_OK;
+}
+
+int caco_finalize_weights(caco_model* m) {
+  CACO_REQUIRE(m, "caco_finalize_weights: null model");
+  if (m->finalized) return CACO_OK;
+  int rc = build_weights(m);
+  if (rc) return rc;
+  CACO_HIP(hipDeviceSynchronize());
+  m->pending.clear();
+  m->finalized = true;
+  return CACO_OK;
+}
+
+int caco_set_logit_scale(caco_model* m, float v) {
+  CACO_REQUIRE(m, "null model");
+  m->logit_scale = v;
+  return CACO_OK;
+}
+float caco_get_logit_scale(const caco_model* m) { return m ? m->logit_scale : 0.f; }
+int64_t caco_workspace_bytes(const caco_model* m) { return m ? (int64_t)m->ws_bytes : 0; }
+int32_t caco_set_gemm_tile(int32_t tile) { return set_gemm_tile_config(tile); }
+
+int caco_profile_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return CACO_OK;
+}
+
+int64_t caco_profile_report(char* buf, int64_t buflen) {
+  std::map<std::string, std::pair<double, long>> acc;
+  for (ProfRec& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& e = acc[r.name];
+      e.first += ms;
+      e.second += 1;
+    }
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : acc) {
+    char tmp[256];
+    snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"ms\": %.6f, \"n\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first,
+             kv.second.second);
+    js += tmp;
+    first = false;
+  }
+  js += "}";
+  if (buf && buflen > 0) {
+    const size_t n = js.size() < (size_t)buflen - 1 ? js.size() : (size_t)buflen - 1;
+    memcpy(buf, js.data(), n);
+    buf[n] = 0;
+  }
+  return (int64_t)js.size() + 1;
+}
+
+int64_t caco_mel_num_frames(int64_t n_samples) { return (n_samples + 159) / 160; }
+
+int caco_mel_spectrogram(const float* wav, int32_t batch, int64_t n_samples, float scale, float bias, float* mel, void* stream) {
+  return mel_frontend(wav, batch, n_samples, 0, scale, bias, mel, MEL_NATURAL_F32, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int caco_mel_patches(const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float scale, float bias,
+                     void* patches, int32_t dtype, float* tinds, float* finds, float* mask, void* stream) {
+  CACO_REQUIRE(dtype == CACO_DTYPE_F32 || dtype == CACO_DTYPE_BF16, "caco_mel_patches: patch dtype %d unknown", dtype);
+  return mel_frontend(wav, batch, n_samples, max_patches, scale, bias, patches,
+                      dtype == CACO_DTYPE_BF16 ? MEL_PATCH_BF16 : MEL_PATCH_F32, tinds, finds, mask, (hipStream_t)stream);
+}
+
+int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const float* tinds, const float* finds,
+                       const float* mask, int32_t batch, int32_t seq, int32_t normalize, float* emb, float* hidden,
+                       void* stream) {
+  CACO_TRY(check_audio_shapes(m, batch, seq));
+  CACO_REQUIRE(patches && tinds && finds && mask && emb, "caco_audio_forward: null argument");
+  CACO_REQUIRE(m->pool_query, "caco_audio_forward: model has no audio pooler (AudioMAE-only weights)");
+  hipStream_t st = (hipStream_t)stream;
+  const caco_config& c = m->cfg;
+  const int H = c.audio_hidden, P = c.patch_size;
+  const int64_t M = (int64_t)batch * seq;
+  Arena A(m);
+  AudioWs w;
+  w.plan(A, M, batch, seq, H, c.audio_intermediate);
+  const size_t o_pb = A.reserve((size_t)M * P * 2);
+  const size_t o_hid = A.reserve((size_t)M * H * 4);
+  const size_t o_kv = A.reserve((size_t)M * 2 * H * 2);
+  const size_t o_pool = A.reserve((size_t)batch * H * 4);
+  const size_t o_emb = A.reserve((size_t)batch * c.projection_size * 4);
+  CACO_TRY(A.commit(st));
+  float* x = A.at<float>(w.x);
+  bf16_t* h = A.at<bf16_t>(w.h);
+  const bf16_t* pb = nullptr;
+  CACO_STAGE("audio.patch_cast", patches_as_bf16(patches, dtype, M * P, A.at<bf16_t>(o_pb), &pb, st));
+  // AudioEncoder.forward, mae.py:125-148
+  CACO_STAGE("audio.patch_embed", linear_f32(m->enc.input_proj, pb, M, nullptr, x, st));
+  CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, c.num_freq_patches, st));
+  CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
+  float* hid = hidden ? hidden : A.at<float>(o_hid);
+  CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hid, h, st));
+  // AudioAttentionPooler.forward, caco.py:41-79
+  bf16_t* kv = A.at<bf16_t>(o_kv);
+  CACO_STAGE("audio.pool_kv_gemm", linear_bf16(m->pool_kv, h, M, ACT_NONE, kv, st));
+  float* pooled = A.at<float>(o_pool);
+  const int phd = H / c.pool_heads;
+  CACO_STAGE("audio.pool", attn_pool(kv, m->pool_query, mask, batch, seq, H, c.pool_heads, 1.0f / sqrtf((float)phd), pooled, st));
+  float* e = normalize ? A.at<float>(o_emb) : emb;
+  CACO_STAGE("audio.proj_norm", gemm_f32(pooled, m->pool_out_w, m->pool_out_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
+  if (normalize) CACO_STAGE("audio.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
+  return CACO_OK;
+}
+
+int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, const int64_t* pos_ids, int32_t batch,
+                      int32_t seq, int32_t normalize, float* emb, float* hidden, void* stream) {
+  CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_REQUIRE(m->cfg.has_text, "model was created without the text tower");
+  CACO_REQUIRE(ids && mask && emb && batch > 0 && seq > 0, "caco_text_forward: bad arguments");
+  const caco_config& c = m->cfg;
+  CACO_REQUIRE(pos_ids || seq <= c.text_max_pos, "caco_text_forward: T=%d exceeds max_position_embeddings=%d", seq, c.text_max_pos);
+  hipStream_t st = (hipStream_t)stream;
+  const int H = c.text_hidden, I = c.text_intermediate;
+  const int64_t M = (int64_t)batch * seq;
+  const int S_pad = attn_seq_pad(seq);
+  Arena A(m);
+  const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
+  const size_t o_qk = A.reserve((size_t)M * 2 * H * 2), o_vt = A.reserve((size_t)batch * H * S_pad * 2);
+  const size_t o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
+  const size_t o_mask = A.reserve((size_t)M * 4), o_kv = A.reserve((size_t)M * 2 * H * 2);
+  const size_t o_pool = A.reserve((size_t)batch * H * 4), o_emb = A.reserve((size_t)batch * c.projection_size * 4);
+  CACO_TRY(A.commit(st));
+  float* x = A.at<float>(o_x);
+  float* y = A.at<float>(o_y);
+  bf16_t* xb = A.at<bf16_t>(o_xb);
+  bf16_t* qk = A.at<bf16_t>(o_qk);
+  bf16_t* vt = A.at<bf16_t>(o_vt);
+  bf16_t* o = A.at<bf16_t>(o_o);
+  bf16_t* a = A.at<bf16_t>(o_a);
+  float* fmask = A.at<float>(o_mask);
+  CACO_TRY(mask_i64_to_f32(mask, fmask, M, st));
+  CACO_HIP(hipMemsetAsync(vt, 0, (size_t)batch * H * S_pad * 2, st));
+  // RobertaEmbeddings.forward, roberta.py:35-53
+  CACO_STAGE("text.embed_ln", text_embed_ln(ids, pos_ids, m->word, m->pos, m->type0, m->emb_ln.g, m->emb_ln.b, M, seq, H,
+                                            c.text_vocab, c.text_max_pos, c.text_ln_eps, x, xb, st));
+  // RobertaEncoder: 12 x RobertaLayer.forward (post-LN), roberta.py:191-215
+  const int nl = (int)m->tlayers.size();
+  for (int n = 0; n < nl; ++n) {
+    const TextLayer& L = m->tlayers[n];
+    CACO_STAGE("text.gemm_qk", linear_bf16(L.qk, xb, M, ACT_NONE, qk, st));
+    CACO_STAGE("text.gemm_v", linear_vt(L.v, xb, batch, seq, vt, st));
+    CACO_STAGE("text.attention", attention(qk, vt, fmask, batch, seq, c.text_heads, H / c.text_heads, 1, o, st));
+    CACO_STAGE("text.gemm_out", linear_f32(L.attn_out, o, M, x, y, st));
+    CACO_STAGE("text.ln", layernorm(y, L.ln_attn.g, L.ln_attn.b, M, H, c.text_ln_eps, x, xb, st));
+    CACO_STAGE("text.gemm_fc1", linear_bf16(L.inter, xb, M, ACT_GELU, a, st));
+    CACO_STAGE("text.gemm_fc2", linear_f32(L.out, a, M, x, y, st));
+    float* xo = (n == nl - 1 && hidden) ? hidden : x;
+    CACO_STAGE("text.ln", layernorm(y, L.ln_out.g, L.ln_out.b, M, H, c.text_ln_eps, xo, xb, st));
+  }
+  if (nl == 0 && hidden) CACO_HIP(hipMemcpyAsync(hidden, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+  // AttentionPooler.forward (roberta.py:253-271) + text_proj (caco.py:169)
+  bf16_t* kv = A.at<bf16_t>(o_kv);
+  CACO_STAGE("text.pool_kv_gemm", linear_bf16(m->tpool_kv, xb, M, ACT_NONE, kv, st));
+  float* pooled = A.at<float>(o_pool);
+  CACO_STAGE("text.pool", attn_pool(kv, m->tpool_query, fmask, batch, seq, H, 1, 1.0f / sqrtf((float)H), pooled, st));
+  float* e = normalize ? A.at<float>(o_emb) : emb;
+  CACO_STAGE("text.proj_norm", gemm_f32(pooled, m->text_proj_w, m->text_proj_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
+  if (normalize) CACO_STAGE("text.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
+  return CACO_OK;
+}
+
+int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float* emb,
+                      void* stream) {
+  CACO_TRY(check_audio_shapes(m, batch, max_patches));
+  CACO_REQUIRE(wav && emb && n_samples > 0, "caco_encode_audio: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  // front-end outputs live in their own allocation so that the forward's arena growth cannot move them
+  static thread_local char* fe = nullptr;
+  static thread_local size_t fe_bytes = 0;
+  const size_t n_tok = (size_t)batch * max_patches;
+  const size_t need = n_tok * 256 * 2 + 3 * n_tok * 4 + 1024;
+  if (need > fe_bytes) {
+    CACO_HIP(hipStreamSynchronize(st));
+    if (fe) CACO_HIP(hipFree(fe));
+    fe = nullptr;
+    fe_bytes = 0;
+    CACO_HIP(hipMalloc(reinterpret_cast<void**>(&fe), need));
+    fe_bytes = need;
+  }
+  bf16_t* patches = reinterpret_cast<bf16_t*>(fe);
+  float* tinds = reinterpret_cast<float*>(fe + ((n_tok * 256 * 2 + 255) & ~(size_t)255));
+  float* finds = tinds + n_tok;
+  float* mask = finds + n_tok;
+  CACO_STAGE("mel.patches", mel_frontend(wav, batch, n_samples, max_patches, 0.2f, 0.9f, patches, MEL_PATCH_BF16, tinds, finds, mask, st));
+  return caco_audio_forward(m, patches, CACO_DTYPE_BF16, tinds, finds, mask, batch, max_patches, 1, emb, nullptr, stream);
+}
+
+int caco_similarity(const float* a, int32_t na, const float* t, int32_t nt, int32_t dim, float scale, float* out,
+                    int32_t ld_out, void* stream) {
+  CACO_REQUIRE(a && t && out, "caco_similarity: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  CACO_STAGE("similarity", gemm_f32(a, t, nullptr, out, na, nt, dim, ld_out, scale, st));
+  return CACO_OK;
+}
+
+int caco_l2_normalize(const float* x, int32_t rows, int32_t dim, float* out, void* stream) {
+  return l2_normalize(x, rows, dim, out, (hipStream_t)stream);
+}
+
+int caco_mae_forward(caco_model* m, const void* patches, int32_t dtype, const float* mask, const float* tinds,
+                     const float* finds, const float* rtinds, const float* rfinds, const float* rmask, int32_t batch,
+                     int32_t nv, int32_t nr, float* out, void* stream) {
+  CACO_TRY(check_audio_shapes(m, batch, nv));
+  CACO_REQUIRE(m->cfg.mae_decoder_layers > 0 && m->dec.restore_patch, "caco_mae_forward: model has no AudioMAE decoder");
+  CACO_REQUIRE(patches && mask && tinds && finds && rtinds && rfinds && rmask && out && nr >= 0, "caco_mae_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const caco_config& c = m->cfg;
+  const int H = c.audio_hidden, P = c.patch_size, S = nv + nr;
+  const int64_t Mv = (int64_t)batch * nv, Mr = (int64_t)batch * nr, M = (int64_t)batch * S;
+  Arena A(m);
+  AudioWs w;
+  w.plan(A, M, batch, S, H, c.audio_intermediate);      // sized for the decoder (S >= V); the encoder reuses it
+  const size_t o_pb = A.reserve((size_t)Mv * P * 2), o_tmp = A.reserve((size_t)M * H * 4);
+  const size_t o_mask = A.reserve((size_t)M * 4);
+  CACO_TRY(A.commit(st));
+  float* x = A.at<float>(w.x);
+  bf16_t* h = A.at<bf16_t>(w.h);
+  float* tmp = A.at<float>(o_tmp);
+  float* cmask = A.at<float>(o_mask);
+  const bf16_t* pb = nullptr;
+  CACO_TRY(patches_as_bf16(patches, dtype, Mv * P, A.at<bf16_t>(o_pb), &pb, st));
+  // encoder on the visible patches (mae.py:228-234)
+  CACO_TRY(linear_f32(m->enc.input_proj, pb, Mv, nullptr, x, st));
+  CACO_TRY(add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, Mv, H, c.num_freq_patches, st));
+  CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, nv, c.audio_heads, c.audio_ln_eps, st));
+  CACO_TRY(layernorm(x, m->enc.norm.g, m->enc.norm.b, Mv, H, c.audio_ln_eps, nullptr, h, st));
+  // AudioDecoder.forward (mae.py:166-207)
+  CACO_TRY(linear_f32(m->dec.input_proj, h, Mv, nullptr, tmp, st));                                            // :177
+  CACO_TRY(add_pos_embed(tmp, nullptr, tinds, finds, m->dec.freq_table, Mv, H, c.num_freq_patches, st));       // :179-186
+  CACO_TRY(copy_rows(tmp, x, batch, nv, S, 0, H, st));
+  if (nr > 0) {
+    CACO_TRY(add_pos_embed(tmp, m->dec.restore_patch, rtinds, rfinds, m->dec.freq_table, Mr, H, c.num_freq_patches, st));  // :188-196
+    CACO_TRY(copy_rows(tmp, x, batch, nr, S, nv, H, st));                                                      // :198
+    CACO_HIP(hipMemcpy2DAsync(cmask + nv, (size_t)S * 4, rmask, (size_t)nr * 4, (size_t)nr * 4, batch, hipMemcpyDeviceToDevice, st));
+  }
+  CACO_HIP(hipMemcpy2DAsync(cmask, (size_t)S * 4, mask, (size_t)nv * 4, (size_t)nv * 4, batch, hipMemcpyDeviceToDevice, st));  // :199
+  CACO_TRY(run_audio_layers(m, m->dec.layers, A, w, cmask, batch, S, c.audio_heads, c.audio_ln_eps, st));
+  CACO_TRY(layernorm(x, m->dec.norm.g, m->dec.norm.b, M, H, c.audio_ln_eps, nullptr, h, st));                  // :204
+  return linear_f32(m->dec.output_proj, h, M, nullptr, out, st);                                               // :205
+}
+
+// ---- op-level entry points (bench roofline leg + unit tests) -------------------------------------
+int caco_op_gemm_bf16(const void* a, const void* w, const float* bias, int64_t M, int32_t N, int32_t K, int32_t act,
+                      void* out, void* stream) {
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, N, 0, 0};
+  return gemm_bf16(g, EPI_BF16, act, (hipStream_t)stream);
+}
+int caco_op_gemm_bf16_f32out(const void* a, const void* w, const float* bias, const float* resid, int64_t M, int32_t N,
+                             int32_t K, float* out, void* stream) {
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, resid, out, M, N, K, N, 0, 0};
+  return gemm_bf16(g, EPI_F32, ACT_NONE, (hipStream_t)stream);
+}
+int caco_op_gemm_bf16_vt(const void* a, const void* w, const float* bias, int32_t batch, int32_t seq, int32_t N, int32_t K,
+                         void* vt, void* stream) {
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, vt, (int64_t)batch * seq, N, K, N, seq, attn_seq_pad(seq)};
+  return gemm_bf16(g, EPI_VT, ACT_NONE, (hipStream_t)stream);
+}
+int caco_op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int32_t dim, float eps, float* of,
+                      void* ob, void* stream) {
+  return layernorm(x, g, b, rows, dim, eps, of, (bf16_t*)ob, (hipStream_t)stream);
+}
+int32_t caco_attn_seq_pad(int32_t seq) { return attn_seq_pad(seq); }
+int caco_op_attention(const void* qk, const void* vt, const float* mask, int32_t batch, int32_t seq, int32_t heads,
+                      int32_t head_dim, int32_t causal, void* out, void* stream) {
+  CACO_REQUIRE(qk && vt && out, "caco_op_attention: null argument");
+  return attention((const bf16_t*)qk, (const bf16_t*)vt, mask, batch, seq, heads, head_dim, causal, (bf16_t*)out,
+                   (hipStream_t)stream);
+}
+
+}  // extern "C"

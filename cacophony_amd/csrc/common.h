@@ -1,0 +1,60 @@
+// Shared device/host helpers for the Cacophony gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CACO_WAVE 64
+
+namespace caco {
+
+// error plumbing shared by all translation units (defined in api.hip)
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define CACO_HIP(call)                                   \
+  do {                                                   \
+    int _st = caco::check_hip((call), #call);            \
+    if (_st) return _st;                                 \
+  } while (0)
+
+#define CACO_REQUIRE(cond, ...)                          \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      caco::set_error(__VA_ARGS__);                      \
+      return CACO_ERR_INVALID;                           \
+    }                                                    \
+  } while (0)
+
+enum { CACO_OK_ = 0 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// host: fp32 -> bf16 round-to-nearest-even
+static inline uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+}  // namespace caco

@@ -1,0 +1,57 @@
+// Internal launcher interface between the kernel translation units and the C-ABI layer (api.hip).
+#pragma once
+#include "common.h"
+#include "../../include/caco_hip.h"
+
+namespace caco {
+
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_VT = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
+
+struct GemmArgs {
+  const bf16_t* A;      // [M, K]
+  const bf16_t* W;      // [N, K]
+  const float* bias;    // [N] or null
+  const float* resid;   // EPI_F32: [M, ldc] fp32 or null (may alias out)
+  void* out;            // EPI_BF16: bf16 [M, ldc]; EPI_F32: fp32 [M, ldc]; EPI_VT: bf16 [M/seq, N, seq_pad]
+  int64_t M;
+  int N, K, ldc;
+  int seq, seq_pad;     // EPI_VT only
+};
+
+int gemm_tile_config();
+int set_gemm_tile_config(int tile);
+int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
+int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
+             hipStream_t st);
+
+// norm.hip
+int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
+              bf16_t* out_bf16, hipStream_t st);
+int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st);
+int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                  const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
+                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st);
+// x[m, :] (+)= sincos(time[m]) + freq_table[freq[m], :] (+ base[:] when base != null, replacing x)
+int add_pos_embed(float* x, const float* base, const float* time_inds, const float* freq_inds, const float* freq_table,
+                  int64_t rows, int dim, int num_freq, hipStream_t st);
+int mask_i64_to_f32(const int64_t* in, float* out, int64_t n, hipStream_t st);
+int cast_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st);
+// dst[b, dst_off + s, :] = src[b, s, :]  (fp32 rows of `dim`; used to concatenate decoder tokens)
+int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq, int dst_off, int dim, hipStream_t st);
+
+// attention.hip
+int attn_seq_pad(int seq);
+int attention(const bf16_t* qk, const bf16_t* vt, const float* key_mask, int batch, int seq, int heads, int head_dim,
+              int causal, bf16_t* out, hipStream_t st);
+
+// pool.hip: learned-query attention pooling over kv[b, s, 0:H | H:2H] (bf16) -> out fp32 [B, H]
+int attn_pool(const bf16_t* kv, const float* query, const float* mask, int batch, int seq, int hidden, int heads,
+              float scale, float* out, hipStream_t st);
+
+// mel.hip
+int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias,
+                 void* out, int mode, float* tinds, float* finds, float* mask, hipStream_t st);
+enum { MEL_NATURAL_F32 = 0, MEL_PATCH_F32 = 1, MEL_PATCH_BF16 = 2 };
+
+}  // namespace caco

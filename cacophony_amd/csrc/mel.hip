@@ -1,0 +1,354 @@
+// Fused front end: 16 kHz waveform -> STFT magnitude -> HTK mel filterbank -> log -> 16x16 patches.
+//
+// Replaces compute_mel_spectrogram + spectrogram_to_patches + the four H2D copies of
+// prepare_audio_batch (src/eval/eval_caco_torch.py:41-151,181-206) with one kernel whose only HBM
+// traffic is the sample buffer in (coalesced float4) and the patch rows out (16-byte stores, already
+// in the encoder's [B, S, 256] token layout, bf16 for the GEMM or fp32 for API parity).
+//
+// Geometry is the reference's fixed front end: hop 160, periodic Hann(400) centred in a 512-point
+// frame (56 zeros each side, torch.stft semantics, eval_caco_torch.py:81-89), |rFFT| (power 1, :91),
+// 128 HTK mel filters over 257 bins (:94-103), log(x + 1e-5) * scale + bias (:104).
+//
+// One workgroup = 256 threads = 16 consecutive frames (= one row of 8 patches) x 16 threads per
+// frame.  The 512-point real FFT is a 256-point complex FFT of the even/odd packed frame, done as
+// two register-resident radix-16 passes with one transposition through LDS, then the real-input
+// split.  The Hann window, the FFT twiddles and the mel filterbank (CSR: 506 non-zero weights) are
+// staged in LDS once per workgroup.  fp32 throughout.
+#include <math.h>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace caco {
+namespace {
+
+constexpr int HOP = 160, WIN = 400, NFFT = 512, NMEL = 128, NBIN = 257, WOFF = (NFFT - WIN) / 2;
+constexpr int FPB = 16;                               // frames per workgroup
+constexpr int SPAN = (FPB - 1) * HOP + WIN;           // 2800 samples feed one workgroup
+constexpr int SPAN_PAD = 2816;
+constexpr int MELW_MAX = 640;
+
+struct MelTables {            // device image, loaded verbatim into LDS
+  float hann[WIN];
+  float tw256[512];           // e^{-2 pi i n1 k2 / 256}, index (n1*16 + k2), interleaved re/im
+  float tw512[516];           // e^{-2 pi i k / 512}, k = 0..256 (+ pad)
+  float melw[MELW_MAX];       // CSR weights
+  int mel_start[NMEL];        // first bin of filter m
+  int mel_off[NMEL];          // offset of its weights in melw
+  int mel_cnt[NMEL];          // number of non-zero bins
+};
+static_assert(sizeof(MelTables) % 16 == 0, "MelTables must be float4-copyable");
+
+constexpr int XP = 272;       // complex pitch per frame: 16*17, and 2*XP = 32 (mod 64) banks
+constexpr int MP = 260;       // magnitude pitch per frame (floats)
+
+struct __attribute__((aligned(16))) MelSmem {
+  float samp[SPAN_PAD];             // samples, later the [16][128] log-mel tile
+  MelTables tab;
+  float2 buf[FPB * XP];             // FFT transposition / spectrum, later magnitudes
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+// forward 4-point DFT (W4 = -i)
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+  const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = mul_mi(csub(x1, x3));
+  x0 = cadd(s02, s13);
+  x2 = csub(s02, s13);
+  x1 = cadd(d02, d13);
+  x3 = csub(d02, d13);
+}
+
+// forward 16-point DFT in registers, natural order in and out (two radix-4 passes).
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  // pass 1: for each b, DFT4 over a of v[b + 4a]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dft4(v[b], v[b + 4], v[b + 8], v[b + 12]);
+  // now v[b + 4c] = y[b][c]; twiddle by W16^{b c}
+  v[1 + 4] = cmul(v[1 + 4], make_float2(C1, -S1));        // bc = 1
+  v[1 + 8] = cmul(v[1 + 8], make_float2(R2, -R2));        // 2
+  v[1 + 12] = cmul(v[1 + 12], make_float2(S1, -C1));      // 3
+  v[2 + 4] = cmul(v[2 + 4], make_float2(R2, -R2));        // 2
+  v[2 + 8] = mul_mi(v[2 + 8]);                            // 4
+  v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, -R2));     // 6
+  v[3 + 4] = cmul(v[3 + 4], make_float2(S1, -C1));        // 3
+  v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, -R2));       // 6
+  v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, S1));      // 9
+  // pass 2: for each c, DFT4 over b of y[b][c] -> X[c + 4d]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+  // v[4c + d] holds X[c + 4d]: transpose the 4x4 index grid back to natural order
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = c + 1; d < 4; ++d) {
+      const float2 tmp = v[4 * c + d];
+      v[4 * c + d] = v[4 * d + c];
+      v[4 * d + c] = tmp;
+    }
+}
+
+// MODE: MEL_NATURAL_F32 -> out fp32 [B, frames_out, 128]; MEL_PATCH_F32 / MEL_PATCH_BF16 -> [B, S, 256]
+template <int MODE>
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int64_t n_samples,
+                                                  const MelTables* __restrict__ tables, void* __restrict__ out,
+                                                  int frames_out, int rows_out, int S, float scale, float bias) {
+  __shared__ MelSmem sm;
+  const int tid = threadIdx.x, fl = tid >> 4, t = tid & 15;
+  const int blk = blockIdx.x, b = blockIdx.y;
+  const int f0 = blk * FPB;
+  const float* w = wav + (int64_t)b * n_samples;
+  const int64_t g0 = (int64_t)f0 * HOP + WOFF;
+
+  // ---- stage constant tables and the sample span -------------------------------------------------
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(tables);
+    f32x4* dst = reinterpret_cast<f32x4*>(&sm.tab);
+    for (int i = tid; i < (int)(sizeof(MelTables) / 16); i += 256) dst[i] = src[i];
+  }
+  if ((n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(wav) & 15) == 0) {
+    for (int i = tid; i < SPAN / 4; i += 256) {
+      const int64_t g = g0 + 4 * i;
+      f32x4 v;
+      if (g + 3 < n_samples) {
+        v = *reinterpret_cast<const f32x4*>(w + g);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (g + r < n_samples) ? w[g + r] : 0.f;   // zero pad, :78
+      }
+      *reinterpret_cast<f32x4*>(&sm.samp[4 * i]) = v;
+    }
+  } else {
+    for (int i = tid; i < SPAN; i += 256) sm.samp[i] = (g0 + i < n_samples) ? w[g0 + i] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
+  float2 v[16];
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) {
+    const int n = t + 16 * n2;                 // complex index; real samples 2n, 2n+1 of the 512 frame
+    float2 z = make_float2(0.f, 0.f);
+    if (n >= WOFF / 2 && n < (WOFF + WIN) / 2) {
+      const int wi = 2 * n - WOFF;             // window tap of the even sample
+      const float2 x = *reinterpret_cast<const float2*>(&sm.samp[fl * HOP + wi]);
+      const float2 h = *reinterpret_cast<const float2*>(&sm.tab.hann[wi]);
+      z = make_float2(x.x * h.x, x.y * h.y);
+    }
+    v[n2] = z;
+  }
+  dft16(v);
+  {
+    const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw256) + t * 16;
+    float2* col = sm.buf + fl * XP + t * 17;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2]);
+  }
+  __syncthreads();
+  // ---- pass B: thread k2 = t transforms over n1 -> X[k2 + 16 k1] -----------------------------------
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = sm.buf[fl * XP + n1 * 17 + t];
+  dft16(v);
+  __syncthreads();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) sm.buf[fl * XP + t + 16 * k1] = v[k1];
+  __syncthreads();
+
+  // ---- real-input split + magnitude: R[k] = ((Zk + conj Z-k) - i w^k (Zk - conj Z-k)) / 2 ----------
+  float mag[17];
+  {
+    const float2* X = sm.buf + fl * XP;
+    const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw512);
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+      const int k = t + 16 * j;
+      float m = 0.f;
+      if (k <= 256) {
+        const float2 zk = X[k & 255];
+        const float2 zr = X[(256 - k) & 255];
+        const float2 zc = make_float2(zr.x, -zr.y);
+        const float2 e = cadd(zk, zc), d = csub(zk, zc);
+        const float2 wd = cmul(tw[k], d);
+        const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
+        m = sqrtf(re * re + im * im);
+      }
+      mag[j] = m;
+    }
+  }
+  __syncthreads();
+  float* magbuf = reinterpret_cast<float*>(sm.buf) + fl * MP;
+#pragma unroll
+  for (int j = 0; j < 17; ++j) {
+    const int k = t + 16 * j;
+    if (k <= 256) magbuf[k] = mag[j];
+  }
+  __syncthreads();
+
+  // ---- mel filterbank (CSR gather) + log; thread owns mels t, t+16, ... ------------------------------
+  float* tile = sm.samp;                      // [16 frames][128 mels]; the samples are dead
+#pragma unroll
+  for (int j = 0; j < NMEL / 16; ++j) {
+    const int m = t + 16 * j;
+    const int st = sm.tab.mel_start[m], off = sm.tab.mel_off[m], cnt = sm.tab.mel_cnt[m];
+    float acc = 0.f;
+    for (int i = 0; i < cnt; ++i) acc += magbuf[st + i] * sm.tab.melw[off + i];
+    tile[fl * NMEL + m] = logf(acc + 1e-5f) * scale + bias;
+  }
+  __syncthreads();
+
+  // ---- coalesced 16/32-byte stores -----------------------------------------------------------------
+  if constexpr (MODE == MEL_NATURAL_F32) {
+    const int frame = f0 + (tid >> 4);
+    if (frame < frames_out) {
+      const int m0 = (tid & 15) * 8;
+      float* op = reinterpret_cast<float*>(out) + ((int64_t)b * frames_out + frame) * NMEL + m0;
+      const float* tp = tile + (tid >> 4) * NMEL + m0;
+      *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
+      *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
+    }
+  } else {
+    // patch row p = blk*8 + f holds mel[f0 + tt][f*16 + m], tt-major (eval_caco_torch.py:124-129)
+    const int f = tid >> 5, rem = tid & 31, tt = rem >> 1, m0 = (rem & 1) * 8;
+    const int p = blk * 8 + f;
+    if (p < rows_out) {
+      const float* tp = tile + tt * NMEL + f * 16 + m0;
+      const int64_t o = ((int64_t)b * S + p) * 256 + tt * 16 + m0;
+      if constexpr (MODE == MEL_PATCH_BF16) {
+        bf16x8 pk;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pk[r] = (bf16_t)tp[r];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + o) = pk;
+      } else {
+        float* op = reinterpret_cast<float*>(out) + o;
+        *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
+        *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
+      }
+    }
+  }
+}
+
+// zero rows [valid, S) of the patch tensor and write time / freq indices and mask
+// (spectrogram_to_patches, eval_caco_torch.py:132-144)
+template <typename T>
+__global__ void patch_meta_kernel(T* __restrict__ patches, float* __restrict__ tinds, float* __restrict__ finds,
+                                  float* __restrict__ mask, int S, int valid, int nfreq) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= S) return;
+  const int lane = threadIdx.x & 63;
+  const bool keep = p < valid;
+  if (lane == 0) {
+    const int q = keep ? p : 0;
+    if (tinds) tinds[(int64_t)b * S + p] = (float)(q / nfreq);
+    if (finds) finds[(int64_t)b * S + p] = (float)(q % nfreq);
+    if (mask) mask[(int64_t)b * S + p] = keep ? 1.f : 0.f;
+  }
+  if (!keep) {
+    T* row = patches + ((int64_t)b * S + p) * 256;
+    for (int i = lane; i < 256; i += 64) row[i] = (T)0.f;
+  }
+}
+
+MelTables* g_tables = nullptr;   // device copy, created once per process (single device per process)
+
+int ensure_tables() {
+  if (g_tables) return CACO_OK;
+  std::vector<char> hostbuf(sizeof(MelTables), 0);
+  MelTables* h = reinterpret_cast<MelTables*>(hostbuf.data());
+  const double PI = 3.14159265358979323846;
+  for (int k = 0; k < WIN; ++k) h->hann[k] = (float)(0.5 - 0.5 * cos(2.0 * PI * k / WIN));   // periodic
+  for (int n1 = 0; n1 < 16; ++n1)
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const double a = -2.0 * PI * (double)(n1 * k2) / 256.0;
+      h->tw256[2 * (n1 * 16 + k2)] = (float)cos(a);
+      h->tw256[2 * (n1 * 16 + k2) + 1] = (float)sin(a);
+    }
+  for (int k = 0; k <= 256; ++k) {
+    const double a = -2.0 * PI * (double)k / 512.0;
+    h->tw512[2 * k] = (float)cos(a);
+    h->tw512[2 * k + 1] = (float)sin(a);
+  }
+  // torchaudio.functional.melscale_fbanks(257, 0, 8000, 128, 16000, norm=None, mel_scale="htk")
+  const double f_max = 8000.0, m_max = 2595.0 * log10(1.0 + f_max / 700.0);
+  std::vector<double> f_pts(NMEL + 2);
+  for (int i = 0; i < NMEL + 2; ++i) f_pts[i] = 700.0 * (pow(10.0, (m_max * i / (NMEL + 1)) / 2595.0) - 1.0);
+  int off = 0;
+  for (int m = 0; m < NMEL; ++m) {
+    int start = -1, cnt = 0;
+    for (int k = 0; k < NBIN; ++k) {
+      const double f = 8000.0 * k / (NBIN - 1);
+      const double down = (f - f_pts[m]) / (f_pts[m + 1] - f_pts[m]);
+      const double up = (f_pts[m + 2] - f) / (f_pts[m + 2] - f_pts[m + 1]);
+      const double wgt = fmax(0.0, fmin(down, up));
+      if (wgt > 0.0) {
+        if (start < 0) start = k;
+        if (k != start + cnt || off + cnt >= MELW_MAX) {
+          set_error("mel filterbank: non-contiguous support or table overflow at filter %d", m);
+          return CACO_ERR_INVALID;
+        }
+        h->melw[off + cnt] = (float)wgt;
+        ++cnt;
+      }
+    }
+    h->mel_start[m] = start < 0 ? 0 : start;
+    h->mel_off[m] = off;
+    h->mel_cnt[m] = cnt;
+    off += cnt;
+  }
+  MelTables* d = nullptr;
+  CACO_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(MelTables)));
+  CACO_HIP(hipMemcpy(d, h, sizeof(MelTables), hipMemcpyHostToDevice));
+  g_tables = d;
+  return CACO_OK;
+}
+
+}  // namespace
+
+int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias, void* out,
+                 int mode, float* tinds, float* finds, float* mask, hipStream_t st) {
+  CACO_REQUIRE(wav && out && batch > 0 && n_samples > 0, "mel: bad arguments (batch %d, n_samples %lld)", batch, (long long)n_samples);
+  CACO_REQUIRE(batch <= 65535, "mel: batch %d exceeds the grid limit", batch);
+  int rc = ensure_tables();
+  if (rc) return rc;
+  const int frames = (int)((n_samples + HOP - 1) / HOP);
+  if (mode == MEL_NATURAL_F32) {
+    const dim3 grid((frames + FPB - 1) / FPB, batch);
+    hipLaunchKernelGGL(mel_kernel<MEL_NATURAL_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, 0, 0,
+                       scale, bias);
+    return check_hip(hipGetLastError(), "mel launch");
+  }
+  CACO_REQUIRE(max_patches > 0, "mel: max_patches must be positive");
+  const int n_tp = frames / FPB, nfreq = NMEL / 16;
+  const int full = n_tp * nfreq;
+  const int valid = full < max_patches ? full : max_patches;   // truncation branch keeps the first max_patches
+  const int blocks = (valid + nfreq - 1) / nfreq;
+  if (blocks > 0) {
+    const dim3 grid(blocks, batch);
+    if (mode == MEL_PATCH_BF16)
+      hipLaunchKernelGGL(mel_kernel<MEL_PATCH_BF16>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
+                         max_patches, scale, bias);
+    else
+      hipLaunchKernelGGL(mel_kernel<MEL_PATCH_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
+                         max_patches, scale, bias);
+    rc = check_hip(hipGetLastError(), "mel patch launch");
+    if (rc) return rc;
+  }
+  if (valid < max_patches || tinds || finds || mask) {
+    const dim3 grid((max_patches + 3) / 4, batch);
+    if (mode == MEL_PATCH_BF16)
+      hipLaunchKernelGGL(patch_meta_kernel<bf16_t>, grid, dim3(256), 0, st, reinterpret_cast<bf16_t*>(out), tinds, finds,
+                         mask, max_patches, valid, nfreq);
+    else
+      hipLaunchKernelGGL(patch_meta_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<float*>(out), tinds, finds, mask,
+                         max_patches, valid, nfreq);
+    rc = check_hip(hipGetLastError(), "patch meta launch");
+  }
+  return rc;
+}
+
+}  // namespace caco

@@ -1,0 +1,223 @@
+// Row-wise wavefront-reduced kernels: LayerNorm, RoBERTa embedding gather + LayerNorm,
+// sin-cos / learned positional embedding add, L2 normalisation, small casts.
+// One 64-lane wave owns one row; statistics stay in fp32 registers; every global access is a
+// 16-byte float4 (or 8-byte bf16x4) per lane.  These are HBM-bound passes.
+//
+// Reference ops replaced: nn.LayerNorm (audio_models/mae.py:68,76,123; text_models/roberta.py:32,111,165),
+// RobertaEmbeddings.forward (roberta.py:35-53), get_sin_cos_pos_embed + freq gather
+// (mae.py:102-109,135-142), x / ||x + 1e-10|| (caco.py:144-146,171-173).
+#include "common.h"
+#include "kernels.h"
+
+namespace caco {
+namespace {
+
+constexpr int MAXC = 4;  // float4 chunks per lane -> dim <= 1024
+
+__device__ __forceinline__ void ln_row(f32x4 (&v)[MAXC], int nchunk, int lane, int dim, const float* gamma,
+                                       const float* beta, float eps, float* of, bf16_t* ob) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c * 64 + lane < nchunk) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+  const float mean = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c * 64 + lane < nchunk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[c][r] -= mean;
+        q += v[c][r] * v[c][r];
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nchunk) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + ch * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + ch * 4);
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = v[c][r] * rstd * g[r] + b[r];
+      if (of) *reinterpret_cast<f32x4*>(of + ch * 4) = y;
+      if (ob) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)y[r];
+        *reinterpret_cast<bf16x4*>(ob + ch * 4) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int64_t rows, int dim, float eps,
+                                                        float* __restrict__ of, bf16_t* __restrict__ ob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = dim >> 2;
+  f32x4 v[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c * 64 + lane < nchunk) v[c] = *reinterpret_cast<const f32x4*>(x + row * dim + (c * 64 + lane) * 4);
+  ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
+}
+
+__global__ __launch_bounds__(256) void text_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
+                                                            const float* __restrict__ word, const float* __restrict__ pos,
+                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int64_t rows, int seq, int dim,
+                                                            int vocab, int max_pos, float eps, float* __restrict__ of,
+                                                            bf16_t* __restrict__ ob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int64_t id = ids[row];
+  int64_t pi = pos_ids ? pos_ids[row] : (row % seq);
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);        // host validates; clamp keeps a bad id from faulting
+  pi = pi < 0 ? 0 : (pi >= max_pos ? max_pos - 1 : pi);
+  const int nchunk = dim >> 2;
+  f32x4 v[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nchunk) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(word + id * dim + ch * 4);
+      const f32x4 p = *reinterpret_cast<const f32x4*>(pos + pi * dim + ch * 4);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(type0 + ch * 4);
+      v[c] = (w + p) + t;   // same association as roberta.py:49
+    }
+  }
+  ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
+}
+
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int rows, int dim,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    const float y = x[(int64_t)row * dim + i] + 1e-10f;     // eps joins the vector, not the norm (caco.py:146)
+    s += y * y;
+  }
+  const float inv = 1.0f / sqrtf(wave_sum(s));
+  for (int i = lane; i < dim; i += 64) out[(int64_t)row * dim + i] = x[(int64_t)row * dim + i] * inv;
+}
+
+// x[m, n] = (base ? base[n] : x[m, n]) + sincos(time[m])[n] + freq_table[freq[m]][n]
+// sincos: n < dim/2 -> sin(t * w_n), else cos(t * w_{n - dim/2}); w_i = exp(2 i * (-ln 1e4) / dim)  (mae.py:102-109)
+__global__ __launch_bounds__(256) void add_pos_embed_kernel(float* __restrict__ x, const float* __restrict__ base,
+                                                            const float* __restrict__ time_inds,
+                                                            const float* __restrict__ freq_inds,
+                                                            const float* __restrict__ freq_table, int64_t rows, int dim,
+                                                            int num_freq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float t = time_inds[row];
+  int f = (int)freq_inds[row];     // .long() truncation, mae.py:139
+  f = f < 0 ? 0 : (f >= num_freq ? num_freq - 1 : f);
+  const int half = dim >> 1;
+  const float kf = -9.210340371976184f / (float)dim;  // -ln(10000) / dim
+  for (int ch = lane; ch < (dim >> 2); ch += 64) {
+    f32x4 v = base ? *reinterpret_cast<const f32x4*>(base + ch * 4)
+                   : *reinterpret_cast<const f32x4*>(x + row * dim + ch * 4);
+    const f32x4 fe = *reinterpret_cast<const f32x4*>(freq_table + (int64_t)f * dim + ch * 4);
+    f32x4 te;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = ch * 4 + r;
+      const int i = n < half ? n : n - half;
+      const float ang = t * expf((2.0f * (float)i) * kf);
+      te[r] = n < half ? sinf(ang) : cosf(ang);
+    }
+    v = (v + te) + fe;   // x + time_pos_emb, then + freq_pos_emb (mae.py:141-142)
+    *reinterpret_cast<f32x4*>(x + row * dim + ch * 4) = v;
+  }
+}
+
+__global__ void mask_i64_to_f32_kernel(const int64_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] != 0 ? 1.0f : 0.0f;
+}
+
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + i * 4);
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+    *reinterpret_cast<bf16x4*>(out + i * 4) = o;
+  }
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int src_seq, int dst_seq,
+                                 int dst_off, int dim4, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % dim4);
+  const int64_t r = i / dim4;
+  const int s = (int)(r % src_seq);
+  const int64_t b = r / src_seq;
+  reinterpret_cast<f32x4*>(dst)[(b * dst_seq + dst_off + s) * dim4 + c] = reinterpret_cast<const f32x4*>(src)[i];
+}
+
+}  // namespace
+
+int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
+              bf16_t* out_bf16, hipStream_t st) {
+  CACO_REQUIRE(dim % 4 == 0 && dim > 0 && dim <= 256 * MAXC, "layernorm: dim %d must be a multiple of 4, <= %d", dim, 256 * MAXC);
+  CACO_REQUIRE(rows > 0 && x && gamma && beta && (out_f32 || out_bf16), "layernorm: bad arguments");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
+                     out_f32, out_bf16);
+  return check_hip(hipGetLastError(), "layernorm launch");
+}
+
+int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
+                  const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
+                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st) {
+  CACO_REQUIRE(dim % 4 == 0 && dim <= 256 * MAXC, "text_embed_ln: unsupported dim %d", dim);
+  hipLaunchKernelGGL(text_embed_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, ids, pos_ids, word, pos,
+                     type0, gamma, beta, rows, seq, dim, vocab, max_pos, eps, out_f32, out_bf16);
+  return check_hip(hipGetLastError(), "text_embed_ln launch");
+}
+
+int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st) {
+  CACO_REQUIRE(rows > 0 && dim > 0 && x && out, "l2_normalize: bad arguments");
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, out);
+  return check_hip(hipGetLastError(), "l2_normalize launch");
+}
+
+int add_pos_embed(float* x, const float* base, const float* time_inds, const float* freq_inds, const float* freq_table,
+                  int64_t rows, int dim, int num_freq, hipStream_t st) {
+  CACO_REQUIRE(dim % 8 == 0, "add_pos_embed: dim %d must be a multiple of 8", dim);
+  hipLaunchKernelGGL(add_pos_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, base, time_inds,
+                     freq_inds, freq_table, rows, dim, num_freq);
+  return check_hip(hipGetLastError(), "add_pos_embed launch");
+}
+
+int mask_i64_to_f32(const int64_t* in, float* out, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(mask_i64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n);
+  return check_hip(hipGetLastError(), "mask_i64_to_f32 launch");
+}
+
+int cast_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st) {
+  CACO_REQUIRE(n % 4 == 0, "cast_f32_to_bf16: n must be a multiple of 4");
+  hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, in, out, n / 4);
+  return check_hip(hipGetLastError(), "cast_f32_to_bf16 launch");
+}
+
+int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq, int dst_off, int dim, hipStream_t st) {
+  CACO_REQUIRE(dim % 4 == 0, "copy_rows: dim must be a multiple of 4");
+  const int64_t total = (int64_t)batch * src_seq * (dim / 4);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, src_seq, dst_seq,
+                     dst_off, dim / 4, total);
+  return check_hip(hipGetLastError(), "copy_rows launch");
+}
+
+}  // namespace caco

@@ -1,0 +1,57 @@
+"""Data-parallel scoring: shard clips / captions over ranks, one all-gather, local similarity row block.
+
+Each clip and caption is embedded independently (no cross-sample op anywhere in the encoders), so the
+only exchange on the path is the CLIP-style gather of both L2-normalised embedding banks before the
+global similarity matrix.  One process per GPU; `torch.distributed` backend
+"nccl" is RCCL over xGMI on ROCm; the same host logic runs on "gloo" for the CPU tests.
+
+The reference has no multi-GPU torch path; its precedent is the JAX `pmap('dp')` with replicated
+parameters (src/eval/eval_caco.py:53-64) and the host-side concat before `T @ A.T`
+(src/eval/eval_caco_torch.py:394-398).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank `rank`; earlier ranks take the remainder."""
+    base, rem = divmod(n_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_banks(audio_emb: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
+    """[B, D] x 2 -> one send buffer [B, 2, D] fp32 (1.57 MB per rank at B = 256, D = 768)."""
+    if audio_emb.shape != text_emb.shape:
+        raise ValueError(f"bank shapes differ: {tuple(audio_emb.shape)} vs {tuple(text_emb.shape)}")
+    return torch.stack([audio_emb.float(), text_emb.float()], dim=1).contiguous()
+
+
+def gather_embedding_banks(audio_emb: torch.Tensor, text_emb: torch.Tensor, group: Optional[dist.ProcessGroup] = None
+                           ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all-gather of the packed banks; returns (A_all [W*B, D], T_all [W*B, D]) in rank order.
+
+    Every rank must contribute the same B (weak scaling: fixed per-GPU batch)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return audio_emb.float(), text_emb.float()
+    world = dist.get_world_size(group)
+    send = pack_banks(audio_emb, text_emb)
+    b, _, d = send.shape
+    recv = torch.empty((world * b, 2, d), dtype=send.dtype, device=send.device)   # rank-major concatenation
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv[:, 0, :].contiguous(), recv[:, 1, :].contiguous()
+
+
+def sharded_similarity(audio_emb: torch.Tensor, text_emb: torch.Tensor, scale: float = 1.0,
+                       group: Optional[dist.ProcessGroup] = None, similarity_fn=None) -> torch.Tensor:
+    """This rank's row block  scale * A_local @ T_all^T  of the global [W*B, W*B] matrix.
+
+    `similarity_fn(a, t, scale)` defaults to the HIP fp32-MFMA kernel; the gloo tests inject a checker."""
+    _, t_all = gather_embedding_banks(audio_emb, text_emb, group)
+    if similarity_fn is None:
+        from .model import similarity as similarity_fn      # HIP kernel; raises without the GPU library
+    return similarity_fn(audio_emb.float(), t_all, scale)

@@ -1,0 +1,156 @@
+/*
+ * caco_hip.h  --  C ABI of libcaco_hip.so: the MI355X (gfx950) drop-in for the Cacophony
+ * inference hot path  (waveform -> log-mel patches -> audio / text encoders -> similarity).
+ *
+ * The reference (gzhu06/Cacophony) has no FFI layer: its boundary for this path is a Python
+ * nn.Module method API plus four pre-processing free functions.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference repo root).  The Python binding
+ * a maintainer would add is cacophony_amd/_lib.py (ctypes); see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every pointer whose name ends in _dev is DEVICE memory owned by the
+ *     caller (the library never frees caller memory); `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream).  All work is enqueued on that stream; calls return without
+ *     synchronising unless stated.
+ *   - every function returns CACO_OK (0) or a negative status; caco_last_error() gives the
+ *     message of the calling thread's last failure.  No C++ exceptions cross the boundary.
+ *   - a caco_model owns its weights (bf16 GEMM operands, fp32 everything else) and one workspace
+ *     arena grown on demand; it is NOT re-entrant: one in-flight forward per model.
+ *   - row-major everywhere; Linear weights arrive in torch layout [out, in], fp32.
+ */
+#ifndef CACO_HIP_H
+#define CACO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CACO_OK 0
+#define CACO_ERR_INVALID (-1)   /* bad argument / shape / missing tensor */
+#define CACO_ERR_HIP (-2)       /* a HIP runtime call failed             */
+#define CACO_ERR_STATE (-3)     /* call order (e.g. forward before finalize) */
+
+#define CACO_DTYPE_F32 0
+#define CACO_DTYPE_BF16 1
+
+typedef struct caco_model caco_model;
+
+/* Hyper-parameter contract.  Mirrors AudioTransformerConfig (src/caco_torch/audio_models/mae.py:9-20),
+ * RobertaConfig (src/caco_torch/text_models/roberta.py:11-23), CACOConfig (src/caco_torch/caco.py:17-21);
+ * defaults of create_caco_model() (src/caco_torch/caco.py:264-317) via caco_default_config(). */
+typedef struct caco_config {
+  int32_t audio_hidden, audio_layers, audio_heads, audio_intermediate, patch_size, num_freq_patches;
+  float audio_ln_eps;
+  int32_t text_vocab, text_hidden, text_layers, text_heads, text_intermediate, text_max_pos, text_type_vocab;
+  float text_ln_eps;
+  int32_t projection_size, pool_heads;
+  float logit_scale;
+  int32_t has_audio, has_text;      /* which towers to allocate (AudioMAE-only models set has_text = 0) */
+  int32_t mae_decoder_layers;       /* > 0: also hold an AudioDecoder (mae.py:151-207) of that depth     */
+} caco_config;
+
+const char* caco_version(void);
+const char* caco_last_error(void);
+void caco_default_config(caco_config* cfg);
+
+/* ---- model lifetime + weights: replaces create_caco_model()/load_state_dict
+ *      (src/caco_torch/caco.py:264, src/eval/eval_caco_torch.py:154-169) ------------------------ */
+int caco_create(const caco_config* cfg, caco_model** out);
+void caco_destroy(caco_model* m);
+/* Upload one tensor by its reference state-dict key ("audio_module.layers.3.mlp.fc1.weight", ...;
+ * AudioMAE keys are "encoder.*" / "decoder.*").  host_f32 is HOST memory, fp32, contiguous.
+ * Unknown keys starting with "decoder_module." are accepted and ignored (captioning, out of scope);
+ * any other unknown key, or a shape mismatch, is an error. */
+int caco_load_tensor(caco_model* m, const char* name, const float* host_f32, const int64_t* shape, int32_t ndim);
+/* Verify every required tensor arrived and build the packed bf16 operands.  Synchronises. */
+int caco_finalize_weights(caco_model* m);
+int caco_set_logit_scale(caco_model* m, float logit_scale);
+float caco_get_logit_scale(const caco_model* m);
+
+/* ---- front end --------------------------------------------------------------------------------
+ * caco_mel_num_frames: ceil(n_samples / 160), the frame count of compute_mel_spectrogram
+ * (src/eval/eval_caco_torch.py:66-72). */
+int64_t caco_mel_num_frames(int64_t n_samples);
+/* compute_mel_spectrogram (src/eval/eval_caco_torch.py:41-105), batched:
+ * wav_dev fp32 [batch, n_samples] -> mel_dev fp32 [batch, frames, 128].
+ * Fixed front-end geometry: sr 16000, hop 160, win 400 (periodic Hann, centred in the 512 frame),
+ * n_fft 512, 128 HTK mels, magnitude spectrum, log(x + 1e-5) * scale + bias. */
+int caco_mel_spectrogram(const float* wav_dev, int32_t batch, int64_t n_samples, float scale, float bias,
+                         float* mel_dev, void* stream);
+/* compute_mel_spectrogram + spectrogram_to_patches (src/eval/eval_caco_torch.py:41-151) fused,
+ * = prepare_audio_batch (:181-206) without the host round trip:
+ * wav_dev fp32 [batch, n_samples] -> patches_dev [batch, max_patches, 256] (patch_dtype f32 | bf16),
+ * time_inds_dev / freq_inds_dev / mask_dev fp32 [batch, max_patches] (any of the three may be NULL). */
+int caco_mel_patches(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t max_patches, float scale,
+                     float bias, void* patches_dev, int32_t patch_dtype, float* time_inds_dev, float* freq_inds_dev,
+                     float* mask_dev, void* stream);
+
+/* ---- encoders ---------------------------------------------------------------------------------
+ * CACO.get_audio_embedding (src/caco_torch/caco.py:123-150):
+ * patches [B,S,256] (f32 | bf16), time/freq inds fp32 [B,S], mask fp32 [B,S] (1 = keep)
+ *   -> emb_dev fp32 [B, projection_size]; hidden_dev fp32 [B,S,hidden] or NULL. */
+int caco_audio_forward(caco_model* m, const void* patches_dev, int32_t patch_dtype, const float* time_inds_dev,
+                       const float* freq_inds_dev, const float* mask_dev, int32_t batch, int32_t seq,
+                       int32_t normalize, float* emb_dev, float* hidden_dev, void* stream);
+/* CACO.get_text_embedding (src/caco_torch/caco.py:152-177): ids int64 [B,T], mask int64 [B,T] (1 = keep),
+ * position_ids int64 [B,T] or NULL (= arange(T), text_models/roberta.py:292-293)
+ *   -> emb_dev fp32 [B, projection_size]; hidden_dev fp32 [B,T,hidden] or NULL. */
+int caco_text_forward(caco_model* m, const int64_t* ids_dev, const int64_t* mask_dev, const int64_t* position_ids_dev,
+                      int32_t batch, int32_t seq, int32_t normalize, float* emb_dev, float* hidden_dev, void* stream);
+/* encode_audio of BASELINE.json north_star = mel patches (bf16, on device) + get_audio_embedding(normalize=True). */
+int caco_encode_audio(caco_model* m, const float* wav_dev, int32_t batch, int64_t n_samples, int32_t max_patches,
+                      float* emb_dev, void* stream);
+
+/* ---- scoring ----------------------------------------------------------------------------------
+ * out[i, j] = scale * <a_i, t_j>: CACO.get_contrastive_logits' matmul (src/caco_torch/caco.py:208-210)
+ * and the callers' similarity (src/eval/eval_caco_torch.py:330,398).  fp32 in, fp32 MFMA, fp32 out.
+ * a_dev [na, dim], t_dev [nt, dim], out_dev [na, nt] with row stride ld_out (>= nt). */
+int caco_similarity(const float* a_dev, int32_t na, const float* t_dev, int32_t nt, int32_t dim, float scale,
+                    float* out_dev, int32_t ld_out, void* stream);
+/* x / ||x + 1e-10||_2 per row (src/caco_torch/caco.py:144-146), in place allowed. */
+int caco_l2_normalize(const float* x_dev, int32_t rows, int32_t dim, float* out_dev, void* stream);
+
+/* ---- AudioMAE stage-1 forward: AudioMAE.forward (src/caco_torch/audio_models/mae.py:217-247) -------
+ * visible patches [B,V,256] + restore index sets -> out_dev fp32 [B, V+R, patch_size]. */
+int caco_mae_forward(caco_model* m, const void* patches_dev, int32_t patch_dtype, const float* mask_dev,
+                     const float* time_inds_dev, const float* freq_inds_dev, const float* restore_time_inds_dev,
+                     const float* restore_freq_inds_dev, const float* restore_mask_dev, int32_t batch,
+                     int32_t n_visible, int32_t n_restore, float* out_dev, void* stream);
+
+/* ---- introspection / measurement ---------------------------------------------------------------- */
+int64_t caco_workspace_bytes(const caco_model* m);
+/* Tuning knob: bf16 GEMM workgroup tile, 128 (128x128, 4 waves) or 256 (256x256, 8 waves).  Returns the
+ * tile now in force; any other value only queries.  Default 256, or env CACO_GEMM_TILE at first use. */
+int32_t caco_set_gemm_tile(int32_t tile);
+/* Per-stage timing.  While enabled, every forward records a hipEvent pair around each launch group on the
+ * caller's stream.  caco_profile_report synchronises on them, writes a JSON object
+ * {"audio.gemm_fc1": {"ms": total, "n": launches}, ...} into buf (truncated to buflen) and resets the
+ * accumulators; it returns the number of bytes the full report needs.  Not thread safe. */
+int caco_profile_enable(int32_t on);
+int64_t caco_profile_report(char* buf, int64_t buflen);
+/* Run one bf16 GEMM of the encoder's dominant shape class in isolation (bench.py roofline leg):
+ * out[M,N] (bf16) = act(A[M,K] (bf16) x W[N,K]^T (bf16) + bias).  act: 0 none, 1 SiLU, 2 erf-GELU. */
+int caco_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, int64_t M, int32_t N, int32_t K,
+                      int32_t act, void* out_dev, void* stream);
+/* fp32 out[M,N] = A x W^T + bias + resid (resid may alias out, may be NULL) */
+int caco_op_gemm_bf16_f32out(const void* a_dev, const void* w_dev, const float* bias_dev, const float* resid_dev,
+                             int64_t M, int32_t N, int32_t K, float* out_dev, void* stream);
+/* LayerNorm over the last axis of fp32 x[rows, dim]; out_f32_dev / out_bf16_dev may each be NULL. */
+int caco_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, int64_t rows, int32_t dim,
+                      float eps, float* out_f32_dev, void* out_bf16_dev, void* stream);
+/* Fused softmax(QK^T * scale + mask) V for the encoder layouts: qk_dev bf16 [B*S, 2*H] (Q | K),
+ * vt_dev bf16 [B, H, S_pad] (V transposed, S_pad = caco_attn_seq_pad(S)), key_mask_dev fp32 [B,S] or NULL,
+ * out_dev bf16 [B*S, H].  head_dim in {64, 96}. */
+int32_t caco_attn_seq_pad(int32_t seq);
+int caco_op_attention(const void* qk_dev, const void* vt_dev, const float* key_mask_dev, int32_t batch, int32_t seq,
+                      int32_t heads, int32_t head_dim, int32_t causal, void* out_dev, void* stream);
+/* bf16 GEMM whose output is written transposed per clip: vt[b, n, s] = (A x W^T + bias)[b*S + s, n] */
+int caco_op_gemm_bf16_vt(const void* a_dev, const void* w_dev, const float* bias_dev, int32_t batch, int32_t seq,
+                         int32_t N, int32_t K, void* vt_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CACO_HIP_H */

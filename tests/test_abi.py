@@ -1,0 +1,79 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads here (no GPU), exports every symbol
+include/caco_hip.h declares, the ctypes binding covers the same set, and the product path fails loudly
+(no CPU fallback) when asked to compute without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cacophony_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/caco_hip.h but not exported"
+    assert set(names) == set(_lib._SIGNATURES), "ctypes binding and header disagree"
+    assert lib.caco_version().startswith(b"cacophony_amd")
+
+
+def test_default_config_matches_reference_defaults():
+    lib = _lib.load()
+    cfg = _lib.CacoConfigC()
+    lib.caco_default_config(C.byref(cfg))
+    # create_caco_model(), src/caco_torch/caco.py:264-317
+    assert (cfg.audio_hidden, cfg.audio_layers, cfg.audio_heads, cfg.audio_intermediate) == (768, 12, 8, 3072)
+    assert (cfg.patch_size, cfg.num_freq_patches) == (256, 8)
+    assert (cfg.text_vocab, cfg.text_hidden, cfg.text_layers, cfg.text_heads, cfg.text_max_pos) == (50265, 768, 12, 12, 514)
+    assert (cfg.projection_size, cfg.pool_heads) == (768, 2)
+    assert abs(cfg.logit_scale - 2.6592) < 1e-6 and abs(cfg.audio_ln_eps - 1e-5) < 1e-12
+
+
+def test_host_side_helpers_without_gpu():
+    lib = _lib.load()
+    assert lib.caco_mel_num_frames(160000) == 1000          # eval_caco_torch.py:66-72
+    assert lib.caco_mel_num_frames(12345) == 78
+    assert lib.caco_attn_seq_pad(500) == 512 and lib.caco_attn_seq_pad(32) == 64
+    assert lib.caco_set_gemm_tile(0) in (128, 256)
+
+
+def test_argument_errors_are_status_codes_not_crashes():
+    lib = _lib.load()
+    assert lib.caco_create(None, None) == _lib.CACO_ERR_INVALID
+    assert b"null" in lib.caco_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(lib.caco_similarity(None, 1, None, 1, 768, 1.0, None, 1, None), "similarity")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="exercises the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from cacophony_amd import frontend
+    from cacophony_amd.model import create_caco_model
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        create_caco_model()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        frontend.compute_mel_spectrogram(np.zeros(16000, np.float32))
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cacophony_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f"{f} reaches into oracle/"
+
+
+def test_spectrogram_to_patches_host_mirror_matches_oracle():
+    from cacophony_amd.frontend import spectrogram_to_patches
+    from oracle import caco_oracle as O
+    rng = np.random.default_rng(0)
+    for frames, max_p in ((1000, 500), (300, 500), (300, 100), (43, 16), (15, 8)):
+        spec = rng.standard_normal((frames, 128)).astype(np.float32)
+        a, b = spectrogram_to_patches(spec, 16, 16, max_p), O.spectrogram_to_patches(spec, 16, 16, max_p)
+        for k in b:
+            np.testing.assert_array_equal(a[k], b[k])

@@ -1,0 +1,241 @@
+"""Kernel-level parity on a real MI355X, every call through the C ABI (ctypes).
+
+Checkers: torch fp32 matmul / softmax on the SAME bf16-rounded operands for the MFMA kernels
+(tolerance = bf16 output rounding, 2^-8 relative), and the CPU oracle + the reference-generated
+goldens for the front end.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cacophony_amd import _lib  # noqa: E402
+from cacophony_amd import frontend, synth  # noqa: E402
+from cacophony_amd.model import l2_normalize, similarity  # noqa: E402
+from oracle import caco_oracle as O  # noqa: E402
+from tests.conftest import load_golden  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K,act", [(1000, 768, 256, 0), (4096, 1536, 768, 0), (2500, 3072, 768, 1),
+                                       (2048, 768, 3072, 0), (8192, 3072, 768, 2), (300, 256, 768, 0)])
+def test_gemm_bf16(lib, tile, M, N, K, act):
+    assert lib.caco_set_gemm_tile(tile) == tile
+    a = _rand((M, K), 1).bfloat16()
+    w = _rand((N, K), 2, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 3)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_gemm_bf16(_p(a), _p(w), _p(bias), M, N, K, act, _p(out), _st()))
+    ref = a.float() @ w.float().T + bias
+    if act == 1:
+        ref = torch.nn.functional.silu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 2e-3
+    assert torch.isfinite(out.float()).all()
+    assert (err <= tol).all(), f"max err {err.max().item():.4g} at {ref.flatten()[err.argmax()].item():.4g}"
+    lib.caco_set_gemm_tile(256)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_bf16_f32_residual_inplace(lib, tile):
+    lib.caco_set_gemm_tile(tile)
+    M, N, K = 3001, 768, 3072
+    a = _rand((M, K), 4).bfloat16()
+    w = _rand((N, K), 5, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 6)
+    x = _rand((M, N), 7)
+    ref = a.float() @ w.float().T + bias + x
+    _lib.check(lib.caco_op_gemm_bf16_f32out(_p(a), _p(w), _p(bias), _p(x), M, N, K, _p(x), _st()))
+    torch.cuda.synchronize()
+    assert (x - ref).abs().max().item() < 2e-3
+    out = torch.empty(M, N, device=DEV)
+    _lib.check(lib.caco_op_gemm_bf16_f32out(_p(a), _p(w), None, None, M, N, K, _p(out), _st()))
+    torch.cuda.synchronize()
+    assert (out - a.float() @ w.float().T).abs().max().item() < 2e-3
+    lib.caco_set_gemm_tile(256)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("B,S", [(3, 500), (5, 32), (2, 498), (1, 1500)])
+def test_gemm_bf16_transposed_v_store(lib, tile, B, S):
+    lib.caco_set_gemm_tile(tile)
+    N, K = 768, 768
+    a = _rand((B * S, K), 8).bfloat16()
+    w = _rand((N, K), 9, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 10)
+    sp = lib.caco_attn_seq_pad(S)
+    assert sp % 64 == 0 and sp >= S
+    vt = torch.zeros(B, N, sp, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_gemm_bf16_vt(_p(a), _p(w), _p(bias), B, S, N, K, _p(vt), _st()))
+    ref = (a.float() @ w.float().T + bias).reshape(B, S, N).transpose(1, 2)
+    torch.cuda.synchronize()
+    assert (vt[:, :, :S].float() - ref).abs().max().item() < 0.05
+    assert (vt[:, :, S:] == 0).all()
+    lib.caco_set_gemm_tile(256)
+
+
+def test_gemm_rejects_bad_shapes(lib):
+    a = torch.zeros(64, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        _lib.check(lib.caco_op_gemm_bf16(_p(a), _p(a), None, 64, 128, 100, 0, _p(a), _st()))
+
+
+def test_layernorm(lib):
+    rows, dim = 1003, 768
+    x = _rand((rows, dim), 11, 3.0) + 0.7
+    g, b = _rand((dim,), 12), _rand((dim,), 13)
+    of = torch.empty_like(x)
+    ob = torch.empty(rows, dim, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_layernorm(_p(x), _p(g), _p(b), rows, dim, 1e-5, _p(of), _p(ob), _st()))
+    ref = torch.nn.functional.layer_norm(x, (dim,), g, b, 1e-5)
+    torch.cuda.synchronize()
+    assert (of - ref).abs().max().item() < 2e-5
+    assert (ob.float() - ref).abs().max().item() < 0.04
+
+
+def _attention_ref(qk, v, key_mask, heads, hd, causal):
+    B, S, H2 = qk.shape
+    H = H2 // 2
+    q = qk[..., :H].float().reshape(B, S, heads, hd).transpose(1, 2)
+    k = qk[..., H:].float().reshape(B, S, heads, hd).transpose(1, 2)
+    vv = v.float().reshape(B, S, heads, hd).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    allow = torch.ones(B, 1, S, S, dtype=torch.bool, device=qk.device)
+    if key_mask is not None:
+        allow = allow & (key_mask != 0)[:, None, None, :]
+    if causal:
+        allow = allow & torch.tril(torch.ones(S, S, dtype=torch.bool, device=qk.device))[None, None]
+    s = s.masked_fill(~allow, float("-inf"))
+    return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, S, H)
+
+
+@pytest.mark.parametrize("B,S,heads,hd,causal,valid", [
+    (2, 500, 8, 96, 0, [496, 144]), (3, 32, 12, 64, 1, [32, 12, 1]), (1, 1500, 8, 96, 0, [1496]),
+    (2, 100, 12, 64, 1, [100, 37]), (2, 64, 8, 96, 0, [64, 64]), (1, 130, 8, 96, 1, [129])])
+def test_attention(lib, B, S, heads, hd, causal, valid):
+    H = heads * hd
+    qk = _rand((B, S, 2 * H), 20, 1.5).bfloat16()
+    v = _rand((B, S, H), 21).bfloat16()
+    mask = torch.zeros(B, S, device=DEV)
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    sp = lib.caco_attn_seq_pad(S)
+    vt = torch.zeros(B, H, sp, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :S] = v.transpose(1, 2)
+    out = torch.full((B, S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), _p(mask), B, S, heads, hd, causal, _p(out), _st()))
+    ref = _attention_ref(qk, v, mask, heads, hd, bool(causal))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err < 0.03, f"max err {err}"
+    # no mask pointer == all keys kept
+    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), None, B, S, heads, hd, causal, _p(out), _st()))
+    ref = _attention_ref(qk, v, None, heads, hd, bool(causal))
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+def test_attention_forced_rescale(lib):
+    """A late key that dominates one query row forces the online-softmax rescale branch (max jumps at the last tile)."""
+    B, S, heads, hd = 1, 500, 8, 96
+    H = heads * hd
+    qk = _rand((B, S, 2 * H), 30, 0.5)
+    qk[0, 7, :hd] = 2.0
+    qk[0, 450, H:H + hd] = 4.0        # key 450 of head 0 aligned with query 7
+    qk = qk.bfloat16()
+    v = _rand((B, S, H), 31).bfloat16()
+    vt = torch.zeros(B, H, lib.caco_attn_seq_pad(S), dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :S] = v.transpose(1, 2)
+    out = torch.empty(B, S, H, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), None, B, S, heads, hd, 0, _p(out), _st()))
+    ref = _attention_ref(qk, v, None, heads, hd, False)
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max().item() < 0.03
+    assert (out[0, 7, :hd].float() - v[0, 450, :hd].float()).abs().max().item() < 0.05
+
+
+# ------------------------------------------------------------------ front end vs oracle and reference goldens
+def test_mel_spectrogram_matches_reference_golden():
+    g = load_golden("mel.npz")
+    wav = synth.make_waveforms(2)
+    mel = frontend.mel_spectrogram_device(torch.from_numpy(wav).to(DEV)).cpu().numpy()
+    assert mel.shape == (2, 1000, 128)
+    assert np.abs(mel[0] - g["mel0"]).max() < 1e-3          # fp32 path: SURVEY.md 8d check (5)
+    assert np.abs(mel[1] - g["mel1"].astype(np.float32)).max() < 3e-3
+    assert np.allclose(mel[0][:, 0], math.log(1e-5) * 0.2 + 0.9, atol=1e-5)     # empty HTK filter, SURVEY Q13
+    one = frontend.compute_mel_spectrogram(torch.from_numpy(wav[0]))
+    assert isinstance(one, np.ndarray) and one.shape == (1000, 128)
+    np.testing.assert_array_equal(one, mel[0])
+
+
+@pytest.mark.parametrize("tag,n,max_p", [("short", 12345, 64), ("tiny", 700, 16), ("3s", 48000, 500), ("trunc", 48000, 100)])
+def test_mel_ragged_lengths(tag, n, max_p):
+    g = load_golden("mel.npz")
+    w = synth.make_waveform(7, n_samples=n)
+    mel = frontend.compute_mel_spectrogram(w)
+    assert mel.shape == g[f"{tag}_mel"].shape
+    assert np.abs(mel - g[f"{tag}_mel"]).max() < 1e-3
+    for dt, tol in ((torch.float32, 3e-3), (torch.bfloat16, 2e-2)):
+        p = frontend.mel_patches_device(torch.from_numpy(w).to(DEV), max_p, dt)
+        for k in ("audio_time_inds", "audio_freq_inds", "audio_mask"):
+            np.testing.assert_array_equal(p[k][0].cpu().numpy(), g[f"{tag}_{k}"])
+        got = p["audio_patches"][0].float().cpu().numpy()
+        assert np.abs(got - g[f"{tag}_audio_patches"].astype(np.float32)).max() < tol
+
+
+def test_mel_patches_match_oracle_batch():
+    wav = synth.make_waveforms(3, start=40)
+    ref = O.prepare_audio_batch(wav, 500)
+    p = frontend.mel_patches_device(torch.from_numpy(wav).to(DEV), 500, torch.float32)
+    assert np.abs(p["audio_patches"].cpu().numpy() - ref["audio_patches"]).max() < 1e-3
+    assert p["audio_mask"].sum().item() == 3 * 496
+    for k in ("audio_time_inds", "audio_freq_inds", "audio_mask"):
+        np.testing.assert_array_equal(p[k].cpu().numpy(), ref[k])
+    pb = frontend.mel_patches_device(torch.from_numpy(wav).to(DEV), 500, torch.bfloat16)
+    assert np.abs(pb["audio_patches"].float().cpu().numpy() - ref["audio_patches"]).max() < 2e-2
+    # odd sample count takes the unaligned load path
+    w2 = wav[:, :159999]
+    p2 = frontend.mel_patches_device(torch.from_numpy(np.ascontiguousarray(w2)).to(DEV), 500, torch.float32)
+    ref2 = O.prepare_audio_batch(w2, 500)
+    assert np.abs(p2["audio_patches"].cpu().numpy() - ref2["audio_patches"]).max() < 1e-3
+
+
+def test_similarity_and_normalize_exact_fp32():
+    a = _rand((37, 768), 40)
+    t = _rand((300, 768), 41)
+    an, tn = l2_normalize(a), l2_normalize(t)
+    ref_a = O.l2_normalize(O.get_ops("numpy"), a.cpu().numpy())
+    assert np.abs(an.cpu().numpy() - ref_a).max() < 1e-6
+    sim = similarity(an, tn, 14.28)
+    ref = 14.28 * (an.double() @ tn.double().T)
+    assert (sim.double() - ref).abs().max().item() < 1e-4
+    z = l2_normalize(torch.zeros(2, 768, device=DEV))
+    assert torch.isfinite(z).all() and (z == 0).all()

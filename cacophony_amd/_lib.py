@@ -86,6 +86,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (build it with `python -m cacophony_amd.build`); "
             "cacophony_amd has no CPU fallback")
+    # torch must load ITS bundled HIP runtime (libamdhip64.so.7) first so that this library binds to the same
+    # copy by SONAME; loading /opt/rocm's copy first leaves the process with two runtimes and no visible device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly

@@ -12,7 +12,7 @@ import re
 from typing import List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcaco_hip.so")
+LIB_PATH = os.environ.get("CACO_LIB_PATH") or os.path.join(HERE, "libcaco_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "caco_hip.h")
 
 CACO_OK = 0
@@ -60,6 +60,7 @@ _SIGNATURES = {
     "caco_profile_enable": (C.c_int, [_i32]),
     "caco_profile_report": (_i64, [C.c_char_p, _i64]),
     "caco_op_gemm_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "caco_op_gemm_bf16_strided": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "caco_attn_seq_pad": (_i32, [_i32]),

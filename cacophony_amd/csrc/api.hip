@@ -724,6 +724,11 @@ int caco_op_gemm_bf16(const void* a, const void* w, const float* bias, int64_t M
   GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, N, 0, 0};
   return gemm_bf16(g, EPI_BF16, act, (hipStream_t)stream);
 }
+int caco_op_gemm_bf16_strided(const void* a, int32_t lda, const void* w, int32_t ldw, const float* bias, int64_t M, int32_t N,
+                              int32_t K, int32_t act, void* out, int32_t ldc, void* stream) {
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, ldc, 0, 0, lda, ldw};
+  return gemm_bf16(g, EPI_BF16, act, (hipStream_t)stream);
+}
 int caco_op_gemm_bf16_f32out(const void* a, const void* w, const float* bias, const float* resid, int64_t M, int32_t N,
                              int32_t K, float* out, void* stream) {
   GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, resid, out, M, N, K, N, 0, 0};

@@ -45,7 +45,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): the result is rounded to bf16 right after
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // host: fp32 -> bf16 round-to-nearest-even

@@ -1,18 +1,31 @@
-// bf16 MFMA GEMM for the encoder stacks, and an exact-fp32 MFMA GEMM for the small scoring ops.
+// bf16 MFMA GEMMs for the encoder stacks (dispatch + two of the three kernels), and an exact-fp32 MFMA GEMM for
+// the small scoring ops.
 //
 //   out[M,N] = epilogue( A[M,K] (bf16, row-major) x W[N,K]^T (bf16, torch Linear layout) )
 //
-// Both operands are K-contiguous, which is the natural MFMA feed on CDNA4: every lane's 8-element
-// fragment is one 16-byte LDS read.  Tiles are staged HBM -> LDS with 16-byte direct loads
-// (global_load_lds_dwordx4); the LDS image is lane-linear, so the bank-conflict swizzle is applied
-// to the per-lane SOURCE address and undone on the ds_read side (same involution on both sides).
-// Accumulation is fp32; bias / residual / SiLU / erf-GELU are fused into the epilogue so the
-// activations make one HBM round trip per GEMM.
+// Both operands are K-contiguous, which is the natural MFMA feed on CDNA4: every lane's 8-element fragment is one
+// 16-byte LDS read.  Tiles are staged HBM/L2 -> LDS with 16-byte direct loads (global_load_lds_dwordx4); the LDS
+// image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the
+// ds_read side (same involution on both sides).  Accumulation is fp32; bias / residual / SiLU / erf-GELU are fused
+// into the epilogue so the activations make one HBM round trip per GEMM.
+//
+// Kernels (measurements and the reasoning behind the choice per shape: DESIGN.md section "GEMM"):
+//   gemm_bf16_p8_kernel  (this file) 256x256x64 tile, 8 waves (2 x 4), ONE persistent workgroup per CU, 128 KiB LDS =
+//                        two K-tiles, each split in four 16 KiB half-tiles (B0 B1 A0 A1).  The K-loop runs in
+//                        PHASES of 16 MFMAs (one 64x32 quadrant of the wave's 128x64 output over the whole K-tile);
+//                        every phase reads only the fragments its quadrant still lacks and issues ONE half-tile of
+//                        loads six half-tiles ahead of its use; loads stay in flight across the raw barriers and
+//                        are retired by one counted vmcnt per K-tile.  The two wave rows run one barrier slot apart,
+//                        so on every SIMD one wave issues MFMAs while the other reads LDS.  Highest operand reuse:
+//                        128 FLOP per byte pulled from L2, which is what bounds these GEMMs on MI355X.
+//   gemm_bf16_x_kernel   (gemm_x.hip) 256x128x32 tile, 4 waves, TWO workgroups per CU covering each other's stalls.
+//   gemm_bf16_kernel     (this file) 128x128x64 tile, 4 waves, plain double buffering: small-M shapes.
 //
 // Reference ops replaced: every nn.Linear on the path (audio_models/mae.py:51-52,116,133;
 // nn.MultiheadAttention in/out projections mae.py:69-74; text_models/roberta.py:62-64,110,153,164;
 // caco.py:35-37,113) and their following F.silu / F.gelu / residual adds.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace caco {
@@ -29,6 +42,7 @@ typedef const __attribute__((address_space(1))) void* gbl_vptr;
 // 256-byte LDS bank row (rows are 128 B, so two rows share a bank row).
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
+// Stage ROWS x 64 bf16 (ROWS*128 B) from row-major global memory into a lane-linear LDS image.
 template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int64_t row0, int64_t last_row, int ld, int k0,
                                            char* lds_tile, int wave, int lane) {
@@ -57,79 +71,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-template <int ACT>
-__device__ __forceinline__ float apply_act(float x) {
-  if constexpr (ACT == ACT_SILU) return silu_f(x);
-  if constexpr (ACT == ACT_GELU) return gelu_erf_f(x);
-  return x;
+// One MFMA step.  SWAP (all epilogues but the transposed V store): the weight fragment is the A operand,
+// so that D[i = n][j = m] and every lane owns 4 CONSECUTIVE n of one output row m.
+template <bool SWAP>
+__device__ __forceinline__ f32x4 mma(const bf16x8& xa, const bf16x8& wb, const f32x4& c) {
+  if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int ACT>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
-  constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr bool SWAP = (EPI != EPI_VT);       // SWAP: lane owns 4 consecutive n of one row m
-  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, BUF = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int tiles_n = p.N / BN;
-  const int tiles_m = (int)((p.M + BM - 1) / BM);
-  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tile_m = t / tiles_n, tile_n = t % tiles_n;
-  const int64_t m0 = (int64_t)tile_m * BM;
-  const int n0 = tile_n * BN;
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  stage_tile<BM, NW>(p.A, m0, p.M - 1, p.K, 0, smem, wave, lane);
-  stage_tile<BN, NW>(p.W, n0, p.N - 1, p.K, 0, smem + A_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int frow = lane & 15, fchunk = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * BUF;
-    if (kt + 1 < nk) {
-      char* nxt = smem + ((kt + 1) & 1) * BUF;
-      stage_tile<BM, NW>(p.A, m0, p.M - 1, p.K, (kt + 1) * BK, nxt, wave, lane);
-      stage_tile<BN, NW>(p.W, n0, p.N - 1, p.K, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
-    }
-    const char* a_t = cur + (wm * (BM / WM)) * ROW_BYTES;
-    const char* b_t = cur + A_BYTES + (wn * (BN / WN)) * ROW_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = lds_frag(a_t, i * 16 + frow, kk * 4 + fchunk);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = lds_frag(b_t, j * 16 + frow, kk * 4 + fchunk);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (SWAP)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ------------------------------------------------------------------ epilogue
-  const int64_t mw = m0 + wm * (BM / WM);
-  const int nw = n0 + wn * (BN / WN);
-  if constexpr (SWAP) {
+// Direct (register -> global) epilogue for the small kernel.
+template <int TM, int TN, int EPI, int ACT>
+__device__ __forceinline__ void epilogue_direct(const f32x4 (&acc)[TM][TN], const GemmArgs& p, int64_t mw, int nw, int lane) {
+  if constexpr (EPI != EPI_VT) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nw + j * 16 + (lane >> 4) * 4;
@@ -143,19 +96,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
         if constexpr (EPI == EPI_BF16) {
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)apply_act<ACT>(v[r]);
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)epi_act<ACT>(v[r]);
           *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.out) + m * p.ldc + n) = o;
         } else {  // EPI_F32: optional residual (may alias out), fp32 store
           float* op = reinterpret_cast<float*>(p.out) + m * p.ldc + n;
           if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldc + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT>(v[r]);
           *reinterpret_cast<f32x4*>(op) = v;
         }
       }
     }
   } else {
-    // transposed per-clip store: vt[b][n][s] <- (m = b*S + s, n); lane owns 4 consecutive m of one n
     bf16_t* vt = reinterpret_cast<bf16_t*>(p.out);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -166,7 +116,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
         const int64_t m4 = mw + i * 16 + (lane >> 4) * 4;
         if (m4 >= p.M) continue;
         const int b = (int)(m4 / p.seq), s = (int)(m4 % p.seq);
-        f32x4 v = acc[i][j];
+        const f32x4 v = acc[i][j];
         if (s + 3 < p.seq && (p.seq & 3) == 0) {
           bf16x4 o;
 #pragma unroll
@@ -187,6 +137,213 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 128x128 tile, plain double buffering
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int EPI, int ACT>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+  constexpr bool SWAP = (EPI != EPI_VT);
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, BUF = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (int)((p.M + BM - 1) / BM);
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage_tile<BM, NW>(p.A, m0, p.M - 1, lda, 0, smem, wave, lane);
+  stage_tile<BN, NW>(p.W, n0, p.N - 1, ldw, 0, smem + A_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * BUF;
+    if (kt + 1 < nk) {
+      char* nxt = smem + ((kt + 1) & 1) * BUF;
+      stage_tile<BM, NW>(p.A, m0, p.M - 1, lda, (kt + 1) * BK, nxt, wave, lane);
+      stage_tile<BN, NW>(p.W, n0, p.N - 1, ldw, (kt + 1) * BK, nxt + A_BYTES, wave, lane);
+    }
+    const char* a_t = cur + (wm * (BM / WM)) * ROW_BYTES;
+    const char* b_t = cur + A_BYTES + (wn * (BN / WN)) * ROW_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = lds_frag(a_t, i * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = lds_frag(b_t, j * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma<SWAP>(af[i], bf[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  epilogue_direct<TM, TN, EPI, ACT>(acc, p, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, persistent, phased K-loop with counted waits
+// ------------------------------------------------------------------------------------------------
+constexpr int HALF_BYTES = 128 * ROW_BYTES;   // 16 KiB half-tile: 128 rows x 64 bf16
+constexpr int TILE_BYTES = 4 * HALF_BYTES;    // B0 B1 A0 A1
+constexpr int P8_SMEM = 2 * TILE_BYTES;       // 128 KiB
+// during an epilogue the next tile's first six half-tiles are landing in buffer 0 and buffer 1's B halves;
+// buffer 1's A halves (32 KiB) are idle and serve as the eight per-wave transpose slabs
+constexpr int P8_SCRATCH_OFF = TILE_BYTES + 2 * HALF_BYTES;
+static_assert(8 * EPI_SCRATCH_BYTES <= 2 * HALF_BYTES, "epilogue slabs must fit in the idle A halves");
+
+// Stream element s = 4 * kt + h of one output tile, h: 0 = B0, 1 = B1, 2 = A0, 3 = A1 (B first: its buffers die first).
+__device__ __forceinline__ void p8_stage(const GemmArgs& p, int s, int nk, int64_t m0, int n0, int lda, int ldw,
+                                         char* smem, int wave, int lane) {
+  const int kt = s >> 2, h = s & 3;
+  if (kt >= nk) return;
+  char* dst = smem + (kt & 1) * TILE_BYTES + h * HALF_BYTES;
+  if (h < 2)
+    stage_tile<128, 8>(p.W, n0 + h * 128, p.N - 1, ldw, kt * BK, dst, wave, lane);
+  else
+    stage_tile<128, 8>(p.A, m0 + (h - 2) * 128, p.M - 1, lda, kt * BK, dst, wave, lane);
+}
+
+// One phase = READ segment (fragment reads + one half-tile of loads + waits) | barrier | 16 MFMAs | barrier.
+#define P8_MFMA_SEGMENT(ACC_I0, ACC_J0, BF)                                                      \
+  __builtin_amdgcn_s_barrier();                                                                 \
+  __builtin_amdgcn_s_setprio(1);                                                                \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
+    acc[ACC_I0 + i][ACC_J0 + jj] = mma<SWAP>(af[i][kk], BF[jj][kk], acc[ACC_I0 + i][ACC_J0 + jj]); \
+  __builtin_amdgcn_s_setprio(0);                                                                \
+  __builtin_amdgcn_s_barrier();
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs p, int skew) {
+  constexpr bool SWAP = (EPI != EPI_VT);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (int)((p.M + 255) / 256);
+  const int nwg = tiles_m * tiles_n;
+  // XCD x owns the contiguous logical tiles [base, base + cnt); its gridDim/8 workgroups deal them round-robin
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  int li = slot;
+  if (li >= cnt) return;
+  const int nk = p.K / BK;
+
+  // De-synchronise the CUs: identical tiles would otherwise march in lock step and hit HBM with every
+  // workgroup's epilogue stores at the same instant.  Each quarter of the workgroups starts a little later.
+  for (int d = (slot & 3) * skew; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  // this wave's operand windows inside a tile buffer: A half wm (all 128 rows), B half wn>>1 (64 of its rows)
+  const int a_off = (2 + wm) * HALF_BYTES;
+  const int b_off = (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * ROW_BYTES;
+  char* sc = smem + P8_SCRATCH_OFF + wave * EPI_SCRATCH_BYTES;
+
+  int t = base + li;
+  int64_t m0 = (int64_t)(t / tiles_n) * 256;
+  int n0 = (t % tiles_n) * 256;
+  // prologue: K-tile 0 complete + the B halves of K-tile 1
+#pragma unroll
+  for (int s = 0; s < 6; ++s) p8_stage(p, s, nk, m0, n0, lda, ldw, smem, wave, lane);
+
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 must have landed in every wave's share before the first read (also retires the previous tile's stores)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // Stagger: wave row 1 runs one barrier slot behind wave row 0.  Every SIMD hosts one wave of each row, so
+    // while one of them issues its 16 MFMAs the other does its LDS reads / load issue, and they swap each slot.
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+    for (int j = 0; j < nk; ++j) {
+      const char* buf = smem + (j & 1) * TILE_BYTES;
+      const char* a_t = buf + a_off;
+      const char* b_t = buf + b_off;
+      const int s0 = 4 * j + 6;
+      // ---- phase 1: quadrant (m0, n0): read B.n0 and A.m0 ---------------------------------------------
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b0f[jj][kk] = lds_frag(b_t, jj * 16 + frow, kk * 4 + fchunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_frag(a_t, i * 16 + frow, kk * 4 + fchunk);
+      p8_stage(p, s0, nk, m0, n0, lda, ldw, smem, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P8_MFMA_SEGMENT(0, 0, b0f)
+      // ---- phase 2: quadrant (m0, n1): read B.n1 ------------------------------------------------------
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b1f[jj][kk] = lds_frag(b_t, 32 + jj * 16 + frow, kk * 4 + fchunk);
+      p8_stage(p, s0 + 1, nk, m0, n0, lda, ldw, smem, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P8_MFMA_SEGMENT(0, 2, b1f)
+      // ---- phase 3: quadrant (m1, n1): read A.m1; K-tile j's B halves are dead from here ----------------
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_frag(a_t, 64 + i * 16 + frow, kk * 4 + fchunk);
+      p8_stage(p, s0 + 2, nk, m0, n0, lda, ldw, smem, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P8_MFMA_SEGMENT(4, 2, b1f)
+      // ---- phase 4: quadrant (m1, n0): B.n0 is still in registers; retire K-tile j+1 --------------------
+      p8_stage(p, s0 + 3, nk, m0, n0, lda, ldw, smem, wave, lane);
+      if (j + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the two newest half-tiles may stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      P8_MFMA_SEGMENT(4, 0, b0f)
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger: every wave executes the same barrier count
+    // every wave has finished reading LDS: start the next tile's loads, then store this tile under them
+    const int64_t m_cur = m0;
+    const int n_cur = n0;
+    li += slots;
+    const bool more = li < cnt;
+    if (more) {
+      t = base + li;
+      m0 = (int64_t)(t / tiles_n) * 256;
+      n0 = (t % tiles_n) * 256;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) p8_stage(p, s, nk, m0, n0, lda, ldw, smem, wave, lane);
+    }
+    wave_epilogue_128x64<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 64, lane, sc);
+    if (!more) break;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int ACT>
 int launch_cfg(const GemmArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
@@ -202,9 +359,41 @@ int launch_cfg(const GemmArgs& p, hipStream_t st) {
 }
 
 template <int EPI, int ACT>
-int launch_epi(const GemmArgs& p, hipStream_t st) {
+int launch_p8(const GemmArgs& p, hipStream_t st) {
+  auto kern = gemm_bf16_p8_kernel<EPI, ACT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM));
+    attr_done = true;
+  }
+  const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
+  static int num_cu = 0;
+  if (!num_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    CACO_HIP(hipGetDevice(&dev));
+    CACO_HIP(hipGetDeviceProperties(&prop, dev));
+    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  static int skew = getenv("CACO_P8_SKEW") ? atoi(getenv("CACO_P8_SKEW")) : 1;
+  const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;     // one resident workgroup per CU (128 KiB LDS)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), P8_SMEM, st, p, tiles > grid ? skew : 0);
+  return check_hip(hipGetLastError(), "gemm_bf16_p8 launch");
+}
+
+template <int EPI, int ACT>
+int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   const int cfg = gemm_tile_config();
-  if (cfg == 256 && p.N % 256 == 0 && p.M >= 2048) return launch_cfg<256, 256, 2, 4, EPI, ACT>(p, st);
+  const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
+  const bool p8_ok = p.N % 256 == 0 && p.K >= 2 * BK;
+  if (cfg == 1256 && p8_ok) return launch_p8<EPI, ACT>(p, st);
+  if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
+  if (cfg == 256) {
+    // chip-filling shapes: the 256x256 persistent kernel (most reuse per L2 byte) when every CU gets >= 2 tiles,
+    // else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128
+    if (p8_ok && tiles_x >= 4 * 256) return launch_p8<EPI, ACT>(p, st);
+    if (tiles_x >= 256) return gemm_bf16_x(p, epi, act, st);
+  }
   return launch_cfg<128, 128, 2, 2, EPI, ACT>(p, st);
 }
 
@@ -219,7 +408,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256) g_tile_cfg = tile;
+  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
   return gemm_tile_config();
 }
 
@@ -228,15 +417,17 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st) {
   CACO_REQUIRE(p.N % 128 == 0, "gemm_bf16: N=%d must be a multiple of 128", p.N);
   CACO_REQUIRE(p.M > 0, "gemm_bf16: M=%lld must be positive", (long long)p.M);
   CACO_REQUIRE(p.A && p.W && p.out, "gemm_bf16: null operand");
+  CACO_REQUIRE((p.lda == 0 || (p.lda >= p.K && p.lda % 8 == 0)) && (p.ldw == 0 || (p.ldw >= p.K && p.ldw % 8 == 0)),
+               "gemm_bf16: operand row strides must be >= K and multiples of 8 elements");
   if (epi == EPI_BF16) {
-    if (act == ACT_NONE) return launch_epi<EPI_BF16, ACT_NONE>(p, st);
-    if (act == ACT_SILU) return launch_epi<EPI_BF16, ACT_SILU>(p, st);
-    if (act == ACT_GELU) return launch_epi<EPI_BF16, ACT_GELU>(p, st);
+    if (act == ACT_NONE) return launch_epi<EPI_BF16, ACT_NONE>(p, st, epi, act);
+    if (act == ACT_SILU) return launch_epi<EPI_BF16, ACT_SILU>(p, st, epi, act);
+    if (act == ACT_GELU) return launch_epi<EPI_BF16, ACT_GELU>(p, st, epi, act);
   } else if (epi == EPI_F32) {
-    if (act == ACT_NONE) return launch_epi<EPI_F32, ACT_NONE>(p, st);
+    if (act == ACT_NONE) return launch_epi<EPI_F32, ACT_NONE>(p, st, epi, act);
   } else if (epi == EPI_VT) {
     CACO_REQUIRE(p.seq > 0 && p.seq_pad >= p.seq, "gemm_bf16: bad seq / seq_pad for the transposed store");
-    if (act == ACT_NONE) return launch_epi<EPI_VT, ACT_NONE>(p, st);
+    if (act == ACT_NONE) return launch_epi<EPI_VT, ACT_NONE>(p, st, epi, act);
   }
   set_error("gemm_bf16: unsupported epilogue %d / activation %d", epi, act);
   return CACO_ERR_INVALID;
@@ -266,16 +457,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  int k = 0;
-  for (; k + 8 <= K; k += 8) {
+  for (int k = 0; k + 8 <= K; k += 8) {
     const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + k);
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + k);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc, 0, 0, 0);
-  }
-  for (; k < K; k += 2) {  // K tail (K even is required by the host wrapper)
-    const float a1 = A[(int64_t)ra * K + k + half], b1 = B[(int64_t)rb * K + k + half];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
   }
   const int n = tn * 32 + (lane & 31);
   if (n >= N) return;

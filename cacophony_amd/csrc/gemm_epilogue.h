@@ -1,0 +1,112 @@
+// Epilogue of one wave's 128 x 64 output tile (8 x 4 MFMA 16x16 blocks, fp32 accumulators), shared by the
+// 256x128 and the 256x256 GEMM kernels.  Bias / activation / residual are applied in registers; each 16-row slab is
+// then transposed through a per-wave LDS scratch slab (4 KiB, XOR-swizzled instead of padded) so that EVERY global
+// store instruction writes whole 128 B (bf16) or 256 B (fp32) row segments instead of the MFMA layout's 32 B pieces.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace caco {
+
+constexpr int EPI_SCRATCH_BYTES = 4096;   // per wave
+
+template <int ACT>
+__device__ __forceinline__ float epi_act(float x) {
+  if constexpr (ACT == ACT_SILU) return silu_f(x);
+  if constexpr (ACT == ACT_GELU) return gelu_erf_f(x);
+  return x;
+}
+
+// acc[i][j]: block (rows mw + 16 i, cols nw + 16 j).  EPI_BF16 / EPI_F32 use the swapped MFMA form
+// (lane = (m = lane & 15, 4 consecutive n at (lane >> 4) * 4)); EPI_VT the direct form (lane = (n, 4 consecutive m)).
+template <int EPI, int ACT>
+__device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], const GemmArgs& p, int64_t mw, int nw,
+                                                     int lane, char* sc) {
+  const int lm = lane & 15, lg = lane >> 4;
+  if constexpr (EPI == EPI_BF16) {
+    constexpr int PITCH = 144;                    // 64 bf16 + 16 B pad
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      b4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + j * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = acc[i][j] + b4[j];
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)epi_act<ACT>(v[r]);
+        *reinterpret_cast<bf16x4*>(sc + lm * PITCH + (j * 16 + lg * 4) * 2) = o;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {            // 8 rows x 128 B per store instruction
+        const int row = tt * 8 + (lane >> 3), c16 = lane & 7;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(sc + row * PITCH + c16 * 16);
+        const int64_t m = mw + i * 16 + row;
+        if (m < p.M) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + m * p.ldc + nw + c16 * 8) = v;
+      }
+    }
+  } else if constexpr (EPI == EPI_F32) {
+    constexpr int PITCH = 256;                    // 64 fp32; 16-byte chunk c of row r lives at chunk c ^ (r & 15)
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      b4[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + j * 16 + lg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(sc + lm * PITCH + (((j * 4 + lg) ^ lm) << 4)) = acc[i][j] + b4[j];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {            // 4 rows x 256 B per store instruction
+        const int row = tt * 4 + (lane >> 4), c4 = lane & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sc + row * PITCH + ((c4 ^ row) << 4));
+        const int64_t m = mw + i * 16 + row;
+        if (m < p.M) {
+          const int64_t o = m * p.ldc + nw + c4 * 4;
+          if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+        }
+      }
+    }
+  } else {
+    // transposed per-clip store vt[b][n][s] <- (m = b*S + s, n)
+    constexpr int PITCH = 256;                    // 128 bf16; 8-byte chunk q of row r lives at chunk q ^ (r & 15)
+    bf16_t* vt = reinterpret_cast<bf16_t*>(p.out);
+    const bool vec = (p.seq & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bs = p.bias ? p.bias[nw + j * 16 + lm] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[i][j][r] + bs);
+        *reinterpret_cast<bf16x4*>(sc + lm * PITCH + (((i * 4 + lg) ^ lm) << 3)) = o;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {            // 2 n-rows x 256 B (128 tokens) per store instruction
+        const int nl = tt * 2 + (lane >> 5), tk = (lane & 31) * 4;
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(sc + nl * PITCH + (((lane & 31) ^ nl) << 3));
+        const int64_t m = mw + tk;
+        const int64_t nrow = (int64_t)(nw + j * 16 + nl);
+        if (m < p.M) {
+          const int b = (int)(m / p.seq), s = (int)(m % p.seq);
+          if (vec && m + 3 < p.M) {
+            *reinterpret_cast<bf16x4*>(vt + ((int64_t)b * p.N + nrow) * p.seq_pad + s) = v;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (m + r < p.M) {
+                const int bb = (int)((m + r) / p.seq), ss = (int)((m + r) % p.seq);
+                vt[((int64_t)bb * p.N + nrow) * p.seq_pad + ss] = v[r];
+              }
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace caco

@@ -17,11 +17,14 @@ struct GemmArgs {
   int64_t M;
   int N, K, ldc;
   int seq, seq_pad;     // EPI_VT only
+  int lda, ldw;         // row strides of A / W in elements; 0 = K (dense)
+  int ngroup;           // gemm_x: n-tiles per L2 group (0 = all)
 };
 
 int gemm_tile_config();
 int set_gemm_tile_config(int tile);
 int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
+int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
              hipStream_t st);
 

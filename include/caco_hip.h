@@ -121,8 +121,10 @@ int caco_mae_forward(caco_model* m, const void* patches_dev, int32_t patch_dtype
 
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 int64_t caco_workspace_bytes(const caco_model* m);
-/* Tuning knob: bf16 GEMM workgroup tile, 128 (128x128, 4 waves) or 256 (256x256, 8 waves).  Returns the
- * tile now in force; any other value only queries.  Default 256, or env CACO_GEMM_TILE at first use. */
+/* Tuning knob: bf16 GEMM kernel choice.  256 (default) = the 256x128 two-workgroups-per-CU kernel when its grid
+ * covers the chip, else the 128x128 kernel; 128 = always 128x128 (env CACO_GEMM_TILE=128 selects it at first use);
+ * 2256 / 1256 = force the 256x128 kernel / the one-workgroup-per-CU 256x256 phased kernel (tests, A/B runs).
+ * Returns the mode now in force; any other value only queries. */
 int32_t caco_set_gemm_tile(int32_t tile);
 /* Per-stage timing.  While enabled, every forward records a hipEvent pair around each launch group on the
  * caller's stream.  caco_profile_report synchronises on them, writes a JSON object
@@ -134,6 +136,9 @@ int64_t caco_profile_report(char* buf, int64_t buflen);
  * out[M,N] (bf16) = act(A[M,K] (bf16) x W[N,K]^T (bf16) + bias).  act: 0 none, 1 SiLU, 2 erf-GELU. */
 int caco_op_gemm_bf16(const void* a_dev, const void* w_dev, const float* bias_dev, int64_t M, int32_t N, int32_t K,
                       int32_t act, void* out_dev, void* stream);
+/* same with explicit row strides (elements) for A, W and out: padded leading dimensions */
+int caco_op_gemm_bf16_strided(const void* a_dev, int32_t lda, const void* w_dev, int32_t ldw, const float* bias_dev, int64_t M,
+                              int32_t N, int32_t K, int32_t act, void* out_dev, int32_t ldc, void* stream);
 /* fp32 out[M,N] = A x W^T + bias + resid (resid may alias out, may be NULL) */
 int caco_op_gemm_bf16_f32out(const void* a_dev, const void* w_dev, const float* bias_dev, const float* resid_dev,
                              int64_t M, int32_t N, int32_t K, float* out_dev, void* stream);

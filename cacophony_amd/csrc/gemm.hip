@@ -387,6 +387,7 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
   const bool p8_ok = p.N % 256 == 0 && p.K >= 2 * BK;
   if (cfg == 1256 && p8_ok) return launch_p8<EPI, ACT>(p, st);
+  if (cfg == 4256 && gemm_bf16_w4_ok(p, epi)) return gemm_bf16_w4(p, epi, act, st);
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
   if (cfg == 256) {
     // chip-filling shapes: the 256x256 persistent kernel (most reuse per L2 byte) when every CU gets >= 2 tiles,
@@ -408,7 +409,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256 || tile == 4256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
   return gemm_tile_config();
 }
 

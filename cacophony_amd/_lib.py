@@ -63,9 +63,7 @@ _SIGNATURES = {
     "caco_op_gemm_bf16_strided": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
-    "caco_attn_seq_pad": (_i32, [_i32]),
-    "caco_op_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "caco_op_gemm_bf16_vt": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_op_attention": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -76,7 +76,7 @@ struct LNp {
 };
 struct AudioLayer {   // AudioEncoderLayer, audio_models/mae.py:64-99
   LNp ln1, ln2;
-  Lin qk, v, o, fc1, fc2;
+  Lin qkv, o, fc1, fc2;
 };
 struct AudioStack {   // AudioEncoder / AudioDecoder trunk
   Lin input_proj;
@@ -87,7 +87,7 @@ struct AudioStack {   // AudioEncoder / AudioDecoder trunk
   Lin output_proj;               // decoder only
 };
 struct TextLayer {    // RobertaLayer, text_models/roberta.py:181-215
-  Lin qk, v, attn_out, inter, out;
+  Lin qkv, attn_out, inter, out;
   LNp ln_attn, ln_out;
 };
 
@@ -216,9 +216,8 @@ struct Builder {
       const std::string p = prefix + ".layers." + std::to_string(n);
       AudioLayer L;
       L.ln1 = ln(p + ".norm1", H);
-      // packed in_proj rows [Wq; Wk; Wv] (torch.nn.MultiheadAttention): Q|K as one GEMM, V as the transposed-store GEMM
-      L.qk = lin_rows(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias", 3 * H, H, 0, 2 * H);
-      L.v = lin_rows(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias", 3 * H, H, 2 * H, H);
+      // packed in_proj rows [Wq; Wk; Wv] (torch.nn.MultiheadAttention): one GEMM, output row = Q | K | V
+      L.qkv = lin_rows(p + ".attn.in_proj_weight", p + ".attn.in_proj_bias", 3 * H, H, 0, 3 * H);
       L.o = lin(p + ".attn.out_proj", H, H);
       L.ln2 = ln(p + ".norm2", H);
       L.fc1 = lin(p + ".mlp.fc1", I, H);
@@ -264,8 +263,7 @@ int build_weights(caco_model* m) {
     for (int n = 0; n < c.text_layers; ++n) {
       const std::string p = "text_module.encoder.layers." + std::to_string(n);
       TextLayer L;
-      L.qk = B.lin_cat({p + ".attention.self.query", p + ".attention.self.key"}, H, H);
-      L.v = B.lin(p + ".attention.self.value", H, H);
+      L.qkv = B.lin_cat({p + ".attention.self.query", p + ".attention.self.key", p + ".attention.self.value"}, H, H);
       L.attn_out = B.lin(p + ".attention.output.dense", H, H);
       L.ln_attn = B.ln(p + ".attention.output.LayerNorm", H);
       L.inter = B.lin(p + ".intermediate.dense", c.text_intermediate, H);
@@ -315,18 +313,13 @@ struct Arena {
 };
 
 int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st) {
-  GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, L.out, 0, 0};
+  GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, L.out};
   return gemm_bf16(g, EPI_BF16, act, st);
 }
 int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st) {
-  GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out, 0, 0};
+  GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out};
   return gemm_bf16(g, EPI_F32, ACT_NONE, st);
 }
-int linear_vt(const Lin& L, const bf16_t* a, int batch, int seq, bf16_t* vt, hipStream_t st) {
-  GemmArgs g{a, L.w, L.b, nullptr, vt, (int64_t)batch * seq, L.out, L.in, L.out, seq, attn_seq_pad(seq)};
-  return gemm_bf16(g, EPI_VT, ACT_NONE, st);
-}
-
 #define CACO_TRY(expr)       \
   do {                       \
     int _rc = (expr);        \
@@ -334,12 +327,11 @@ int linear_vt(const Lin& L, const bf16_t* a, int batch, int seq, bf16_t* vt, hip
   } while (0)
 
 struct AudioWs {
-  size_t x, h, qk, vt, o, a;
+  size_t x, h, qkv, o, a;
   void plan(Arena& A, int64_t M, int batch, int seq, int H, int I) {
     x = A.reserve((size_t)M * H * 4);
     h = A.reserve((size_t)M * H * 2);
-    qk = A.reserve((size_t)M * 2 * H * 2);
-    vt = A.reserve((size_t)batch * H * attn_seq_pad(seq) * 2);
+    qkv = A.reserve((size_t)M * 3 * H * 2);
     o = A.reserve((size_t)M * H * 2);
     a = A.reserve((size_t)M * I * 2);
   }
@@ -352,17 +344,13 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   const int64_t M = (int64_t)batch * seq;
   float* x = A.at<float>(w.x);
   bf16_t* h = A.at<bf16_t>(w.h);
-  bf16_t* qk = A.at<bf16_t>(w.qk);
-  bf16_t* vt = A.at<bf16_t>(w.vt);
+  bf16_t* qkv = A.at<bf16_t>(w.qkv);
   bf16_t* o = A.at<bf16_t>(w.o);
   bf16_t* a = A.at<bf16_t>(w.a);
-  // pad columns of V^T are multiplied by P = 0; they only have to be finite
-  CACO_HIP(hipMemsetAsync(vt, 0, (size_t)batch * H * attn_seq_pad(seq) * 2, st));
   for (const AudioLayer& L : layers) {
     CACO_STAGE("audio.ln", layernorm(x, L.ln1.g, L.ln1.b, M, H, eps, nullptr, h, st));
-    CACO_STAGE("audio.gemm_qk", linear_bf16(L.qk, h, M, ACT_NONE, qk, st));
-    CACO_STAGE("audio.gemm_v", linear_vt(L.v, h, batch, seq, vt, st));
-    CACO_STAGE("audio.attention", attention(qk, vt, mask, batch, seq, heads, H / heads, 0, o, st));
+    CACO_STAGE("audio.gemm_qkv", linear_bf16(L.qkv, h, M, ACT_NONE, qkv, st));
+    CACO_STAGE("audio.attention", attention(qkv, 3 * H, H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
     CACO_STAGE("audio.gemm_out", linear_f32(L.o, o, M, x, x, st));
     CACO_STAGE("audio.ln", layernorm(x, L.ln2.g, L.ln2.b, M, H, eps, nullptr, h, st));
     CACO_STAGE("audio.gemm_fc1", linear_bf16(L.fc1, h, M, ACT_SILU, a, st));
@@ -591,10 +579,9 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   hipStream_t st = (hipStream_t)stream;
   const int H = c.text_hidden, I = c.text_intermediate;
   const int64_t M = (int64_t)batch * seq;
-  const int S_pad = attn_seq_pad(seq);
   Arena A(m);
   const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
-  const size_t o_qk = A.reserve((size_t)M * 2 * H * 2), o_vt = A.reserve((size_t)batch * H * S_pad * 2);
+  const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2);
   const size_t o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
   const size_t o_mask = A.reserve((size_t)M * 4), o_kv = A.reserve((size_t)M * 2 * H * 2);
   const size_t o_pool = A.reserve((size_t)batch * H * 4), o_emb = A.reserve((size_t)batch * c.projection_size * 4);
@@ -602,13 +589,11 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   float* x = A.at<float>(o_x);
   float* y = A.at<float>(o_y);
   bf16_t* xb = A.at<bf16_t>(o_xb);
-  bf16_t* qk = A.at<bf16_t>(o_qk);
-  bf16_t* vt = A.at<bf16_t>(o_vt);
+  bf16_t* qkv = A.at<bf16_t>(o_qkv);
   bf16_t* o = A.at<bf16_t>(o_o);
   bf16_t* a = A.at<bf16_t>(o_a);
   float* fmask = A.at<float>(o_mask);
   CACO_TRY(mask_i64_to_f32(mask, fmask, M, st));
-  CACO_HIP(hipMemsetAsync(vt, 0, (size_t)batch * H * S_pad * 2, st));
   // RobertaEmbeddings.forward, roberta.py:35-53
   CACO_STAGE("text.embed_ln", text_embed_ln(ids, pos_ids, m->word, m->pos, m->type0, m->emb_ln.g, m->emb_ln.b, M, seq, H,
                                             c.text_vocab, c.text_max_pos, c.text_ln_eps, x, xb, st));
@@ -616,9 +601,8 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   const int nl = (int)m->tlayers.size();
   for (int n = 0; n < nl; ++n) {
     const TextLayer& L = m->tlayers[n];
-    CACO_STAGE("text.gemm_qk", linear_bf16(L.qk, xb, M, ACT_NONE, qk, st));
-    CACO_STAGE("text.gemm_v", linear_vt(L.v, xb, batch, seq, vt, st));
-    CACO_STAGE("text.attention", attention(qk, vt, fmask, batch, seq, c.text_heads, H / c.text_heads, 1, o, st));
+    CACO_STAGE("text.gemm_qkv", linear_bf16(L.qkv, xb, M, ACT_NONE, qkv, st));
+    CACO_STAGE("text.attention", attention(qkv, 3 * H, H, 2 * H, fmask, batch, seq, c.text_heads, H / c.text_heads, 1, o, st));
     CACO_STAGE("text.gemm_out", linear_f32(L.attn_out, o, M, x, y, st));
     CACO_STAGE("text.ln", layernorm(y, L.ln_attn.g, L.ln_attn.b, M, H, c.text_ln_eps, x, xb, st));
     CACO_STAGE("text.gemm_fc1", linear_bf16(L.inter, xb, M, ACT_GELU, a, st));
@@ -721,33 +705,27 @@ int caco_mae_forward(caco_model* m, const void* patches, int32_t dtype, const fl
 // ---- op-level entry points (bench roofline leg + unit tests) -------------------------------------
 int caco_op_gemm_bf16(const void* a, const void* w, const float* bias, int64_t M, int32_t N, int32_t K, int32_t act,
                       void* out, void* stream) {
-  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, N, 0, 0};
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, N};
   return gemm_bf16(g, EPI_BF16, act, (hipStream_t)stream);
 }
 int caco_op_gemm_bf16_strided(const void* a, int32_t lda, const void* w, int32_t ldw, const float* bias, int64_t M, int32_t N,
                               int32_t K, int32_t act, void* out, int32_t ldc, void* stream) {
-  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, ldc, 0, 0, lda, ldw};
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, out, M, N, K, ldc, lda, ldw};
   return gemm_bf16(g, EPI_BF16, act, (hipStream_t)stream);
 }
 int caco_op_gemm_bf16_f32out(const void* a, const void* w, const float* bias, const float* resid, int64_t M, int32_t N,
                              int32_t K, float* out, void* stream) {
-  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, resid, out, M, N, K, N, 0, 0};
+  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, resid, out, M, N, K, N};
   return gemm_bf16(g, EPI_F32, ACT_NONE, (hipStream_t)stream);
-}
-int caco_op_gemm_bf16_vt(const void* a, const void* w, const float* bias, int32_t batch, int32_t seq, int32_t N, int32_t K,
-                         void* vt, void* stream) {
-  GemmArgs g{(const bf16_t*)a, (const bf16_t*)w, bias, nullptr, vt, (int64_t)batch * seq, N, K, N, seq, attn_seq_pad(seq)};
-  return gemm_bf16(g, EPI_VT, ACT_NONE, (hipStream_t)stream);
 }
 int caco_op_layernorm(const float* x, const float* g, const float* b, int64_t rows, int32_t dim, float eps, float* of,
                       void* ob, void* stream) {
   return layernorm(x, g, b, rows, dim, eps, of, (bf16_t*)ob, (hipStream_t)stream);
 }
-int32_t caco_attn_seq_pad(int32_t seq) { return attn_seq_pad(seq); }
-int caco_op_attention(const void* qk, const void* vt, const float* mask, int32_t batch, int32_t seq, int32_t heads,
-                      int32_t head_dim, int32_t causal, void* out, void* stream) {
-  CACO_REQUIRE(qk && vt && out, "caco_op_attention: null argument");
-  return attention((const bf16_t*)qk, (const bf16_t*)vt, mask, batch, seq, heads, head_dim, causal, (bf16_t*)out,
+int caco_op_attention(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, const float* mask, int32_t batch,
+                      int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out, void* stream) {
+  CACO_REQUIRE(qkv && out, "caco_op_attention: null argument");
+  return attention((const bf16_t*)qkv, ld, k_off, v_off, mask, batch, seq, heads, head_dim, causal, (bf16_t*)out,
                    (hipStream_t)stream);
 }
 

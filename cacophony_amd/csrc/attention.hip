@@ -5,66 +5,81 @@
 //          torch.nn.MultiheadAttention with key_padding_mask, need_weights=False)
 //   text : 12 heads x 64, T = 32, causal AND key-padding mask          (text_models/roberta.py:86-104,297-310)
 //
-// Layout contract (produced by the QKV GEMMs): qk[B*S, 2H] bf16 with Q in columns [0,H) and K in
-// [H,2H), head h owning the contiguous slice h*HD..; V arrives TRANSPOSED per clip,
-// vt[B, H, S_pad] (S_pad = multiple of 64, written by the GEMM's transposed epilogue), so that both
-// MFMA operands of P.V are k-contiguous and no transpose is needed on chip.
+// Layout contract (produced by ONE fused QKV GEMM): qkv[B*S, 3H] bf16, row = token, columns Q | K | V, head h
+// owning the contiguous slice h*HD.. of each third.  All three operands are consumed in this natural layout:
+// Q and K are k-contiguous MFMA operands as they are; V (key-major) is the transposed operand of P.V and is read
+// from LDS with the gfx950 hardware transpose read (ds_read_b64_tr_b16), so no V^T copy is ever written.
 //
-// Work split: one workgroup = 4 waves = 128 query rows of one (clip, head); each wave owns 32 query
-// rows and the full head dimension.  K / V^T tiles of 64 keys are register-staged into padded
-// (conflict-free) LDS, double-buffered, with the next tile's global loads issued before the
-// current tile's MFMAs (issue-early / write-late).
+// Work split: one workgroup = NW waves = 32*NW query rows of one (clip, head); each wave owns 32 query rows and
+// the full head dimension.  K / V tiles of 64 keys are register-staged into LDS (K rows padded by 16 B, V rows
+// unpadded: both conflict-free for their read patterns), double-buffered, with the next tile's global loads
+// issued before the current tile's MFMAs (issue-early / write-late).
 //
 // Math per 64-key tile, all on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
-//   S^T[key, q] = K Q^T      (operands swapped so that every lane owns ONE query column: the
-//                             row-wise softmax is lane-local plus a single lane^32 exchange)
+//   S^T[key, q] = K Q^T      (operands swapped so that every lane owns ONE query column: the row-wise softmax is
+//                             lane-local plus a single lane^32 exchange)
 //   O^T[d, q]  += V^T P^T
-// The MFMA row <-> key assignment is permuted (bits 2 and 3 swapped) so that the S^T accumulator
-// registers of a lane are, in order, exactly the 8-key groups the P operand of the second MFMA
-// wants: P never leaves registers and needs no cross-lane shuffle.
-// Softmax statistics (running max / sum) are fp32; exp is evaluated as exp2 with the 1/sqrt(HD)
-// scale and log2(e) folded into one multiply.  A query row whose keys are all masked yields 0
-// (the reference yields NaN there; it cannot happen with right-padded inputs).
+// The MFMA row <-> key assignment of the first product is permuted (bits 2 and 3 swapped) so that the S^T
+// accumulator registers of a lane are, in order, exactly the 8-key groups the P operand of the second MFMA wants:
+// P never leaves registers and needs no cross-lane shuffle.
+// Softmax statistics (running max / sum) are fp32.  The running max is kept on the RAW scores; exp is evaluated as
+// exp2(fma(s, scale*log2e, -max*scale*log2e)): one FMA + one v_exp per score.  Mask work (key padding, causal
+// diagonal) is only executed for tiles that contain a masked key; the O rescale only when some row's max moved.
+// A query row whose keys are all masked yields 0 (the reference yields NaN there; it cannot happen with
+// right-padded inputs).
 #include "common.h"
 #include "kernels.h"
 
 namespace caco {
 namespace {
 
-constexpr int QB = 128;        // query rows per workgroup
 constexpr int KT = 64;         // keys per tile
-constexpr int VP = KT * 2 + 16;  // V^T row pitch in bytes (144: 9 x 16 B -> 16 consecutive rows hit 16 slots)
+constexpr int VP = 192;        // V row pitch in bytes (4 consecutive keys' 64-byte segments tile the 256-byte bank row)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 __device__ __forceinline__ int key_perm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
-                                                        const float* __restrict__ key_mask, int S, int S_pad, int heads,
-                                                        bf16_t* __restrict__ out, float scale_log2) {
+// 8 consecutive keys x one head-dim column per lane = A operand of O^T += V^T P^T, from the key-major V tile
+__device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * VP));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
+                                                            const float* __restrict__ key_mask, int S, int heads,
+                                                            bf16_t* __restrict__ out, float scale_log2) {
+  constexpr int NT = NW * 64, QB = NW * 32;
   constexpr int KP = HD * 2 + 16;              // K row pitch (208 / 144 bytes)
-  constexpr int KCH = HD / 8;                  // 16-byte chunks per K row
-  constexpr int NKC = KT * KCH / 256;          // K chunks per thread per tile
-  constexpr int NVC = HD * 8 / 256;            // V^T chunks per thread per tile
+  constexpr int KCH = HD / 8;                  // 16-byte chunks per K / V row
+  constexpr int NCH = (KT * KCH + NT - 1) / NT;  // chunks per thread per tile (the last round may be partial)
   constexpr int KS = HD / 16;                  // MFMA k-steps over the head dim
   constexpr int DT = HD / 32;                  // 32-row output tiles over the head dim
-  constexpr int K_BYTES = KT * KP, V_BYTES = HD * VP, BUF = K_BYTES + V_BYTES + KT * 4;
+  constexpr int K_BYTES = KT * KP, V_BYTES = KT * VP, BUF = K_BYTES + V_BYTES + KT * 4 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int H = heads * HD;
   const int64_t row_base = (int64_t)b * S;
-  const bf16_t* q_base = qk + row_base * (2 * H) + h * HD;
-  const bf16_t* k_base = q_base + H;
-  const bf16_t* v_base = vt + ((int64_t)b * H + h * HD) * S_pad;
+  const bf16_t* q_base = qkv + row_base * ld + h * HD;
+  const bf16_t* k_base = q_base + k_off;
+  const bf16_t* v_base = q_base + v_off;
 
-  const int q_row = qb * QB + wave * 32 + l31;
-  const bool wave_active = (qb * QB + wave * 32) < S;
+  const int q0 = qb * QB + wave * 32;
+  const int q_row = q0 + l31;
+  const bool wave_active = q0 < S;
 
   // Q fragments (B operand: column j = query, k = 8 contiguous head-dim elements)
   bf16x8 qf[KS];
   {
-    const bf16_t* qp = q_base + (int64_t)(q_row < S ? q_row : S - 1) * (2 * H) + hf * 8;
+    const bf16_t* qp = q_base + (int64_t)(q_row < S ? q_row : S - 1) * ld + hf * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
@@ -75,20 +90,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     ntiles = min(ntiles, last_q / KT + 1);
   }
 
-  bf16x8 kreg[NKC], vreg[NVC];
+  bf16x8 kreg[NCH], vreg[NCH];
   float breg = 0.f;
   auto load_tile = [&](int t) {
     const int key0 = t * KT;
 #pragma unroll
-    for (int i = 0; i < NKC; ++i) {
-      const int id = tid + i * 256, r = id / KCH, c = id % KCH;
-      const int key = min(key0 + r, S - 1);
-      kreg[i] = *reinterpret_cast<const bf16x8*>(k_base + (int64_t)key * (2 * H) + c * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int id = tid + i * 256, d = id >> 3, c = id & 7;
-      vreg[i] = *reinterpret_cast<const bf16x8*>(v_base + (int64_t)d * S_pad + key0 + c * 8);
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * NT;
+      if (KT * KCH % NT == 0 || id < KT * KCH) {
+        const int r = id / KCH, c = id % KCH;
+        const int64_t key = min(key0 + r, S - 1);
+        kreg[i] = *reinterpret_cast<const bf16x8*>(k_base + key * ld + c * 8);
+        vreg[i] = *reinterpret_cast<const bf16x8*>(v_base + key * ld + c * 8);
+      }
     }
     if (tid < KT) {
       const int key = key0 + tid;
@@ -100,16 +114,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     char* kb = smem + buf * BUF;
     char* vb = kb + K_BYTES;
 #pragma unroll
-    for (int i = 0; i < NKC; ++i) {
-      const int id = tid + i * 256, r = id / KCH, c = id % KCH;
-      *reinterpret_cast<bf16x8*>(kb + r * KP + c * 16) = kreg[i];
+    for (int i = 0; i < NCH; ++i) {
+      const int id = tid + i * NT;
+      if (KT * KCH % NT == 0 || id < KT * KCH) {
+        const int r = id / KCH, c = id % KCH;
+        *reinterpret_cast<bf16x8*>(kb + r * KP + c * 16) = kreg[i];
+        *reinterpret_cast<bf16x8*>(vb + r * VP + c * 16) = vreg[i];
+      }
     }
-#pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int id = tid + i * 256, d = id >> 3, c = id & 7;
-      *reinterpret_cast<bf16x8*>(vb + d * VP + c * 16) = vreg[i];
+    if (tid < KT) {      // wave 0: per-key additive mask + "this tile has a masked key" flag
+      float* bias = reinterpret_cast<float*>(vb + V_BYTES);
+      bias[tid] = breg;
+      const unsigned long long any = __ballot(breg != 0.f);
+      if (tid == 0) reinterpret_cast<int*>(bias + KT)[0] = any != 0ull;
     }
-    if (tid < KT) reinterpret_cast<float*>(vb + V_BYTES)[tid] = breg;
   };
 
   f32x16 o[DT];
@@ -117,7 +135,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;     // running max of the RAW scores, running sum of exp
+
+  // per-lane part of the transposed V fragment address: 16-lane group (lane >> 4) & 1 selects the 16-column half,
+  // lane >> 5 the 8-key half, (lane & 15) >> 2 the key within a 4-key block, lane & 3 the 4-column piece
+  const int v_lane = (8 * hf + ((lane & 15) >> 2)) * VP + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
 
   load_tile(0);
   store_tile(0);
@@ -141,29 +163,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
           s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
         }
       }
-      // scores -> log2 domain, masks, tile max
+      // masks (only for tiles that have any): s[st][g*8 + e] is key t*64 + st*32 + 16*g + 8*hf + e
+      const bool pad_tile = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(bias + KT)[0]) != 0;
+      const bool diag_tile = CAUSAL && (t * KT + KT - 1 > q0);
+      if (pad_tile || diag_tile) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int kl = st * 32 + 16 * g + 8 * hf;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + kl);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + kl + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = s[st][g * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
+              if (CAUSAL && (t * KT + kl + e) > q_row) v = -INFINITY;
+              s[st][g * 8 + e] = v;
+            }
+          }
+      }
       float m_tile = -INFINITY;
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
+      for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int kl = st * 32 + 16 * g + 8 * hf;     // first of this lane's 8 consecutive keys
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + kl);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + kl + 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int r = g * 8 + e;
-            float v = s[st][r] * scale_log2 + (e < 4 ? b0[e] : b1[e - 4]);
-            if (CAUSAL && (t * KT + kl + e) > q_row) v = -INFINITY;
-            s[st][r] = v;
-            m_tile = fmaxf(m_tile, v);
-          }
-        }
-      }
+        for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[st][r]);
       m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
       const float m_new = fmaxf(m_run, m_tile);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      const float neg = -m_use * scale_log2;
       float psum = 0.f;
       bf16x8 pf[4];
 #pragma unroll
@@ -172,23 +199,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float p = __builtin_amdgcn_exp2f(s[st][g * 8 + e] - m_use);
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][g * 8 + e], scale_log2, neg));
             psum += p;
             pf[st * 2 + g][e] = (bf16_t)p;
           }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
+      if (__ballot(m_new > m_run) != 0ull) {       // some row's max moved: rescale this wave's running state
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2);   // m_run = -inf -> 0
+        l_run *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += psum;
       // O^T += V^T P^T
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const char* vr = vb + (dt * 32 + l31) * VP + hf * 16;
+        const char* vr = vb + v_lane + dt * 64;
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp) {
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vr + sp * 32);
+          const bf16x8 vf = v_frag_tr(vr + sp * 16 * VP);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], o[dt], 0, 0, 0);
         }
       }
@@ -216,18 +247,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 
 }  // namespace
 
-int attn_seq_pad(int seq) { return (seq + KT - 1) / KT * KT; }
-
-int attention(const bf16_t* qk, const bf16_t* vt, const float* key_mask, int batch, int seq, int heads, int head_dim,
-              int causal, bf16_t* out, hipStream_t st) {
+int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
+              int head_dim, int causal, bf16_t* out, hipStream_t st) {
   CACO_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention: bad shape B=%d S=%d heads=%d", batch, seq, heads);
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
-  const int S_pad = attn_seq_pad(seq);
-  const dim3 grid((seq + QB - 1) / QB, heads, batch);
+  CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
+  constexpr int NW = 4;
+  const dim3 grid((seq + NW * 32 - 1) / (NW * 32), heads, batch);
 #define CACO_ATTN(HD_, C_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_>), grid, dim3(256), 0, st, qk, vt, key_mask, seq, S_pad, heads, out, scale_log2)
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2)
   if (head_dim == 96) {
     if (causal) CACO_ATTN(96, true); else CACO_ATTN(96, false);
   } else {

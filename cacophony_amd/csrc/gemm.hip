@@ -71,18 +71,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
-// One MFMA step.  SWAP (all epilogues but the transposed V store): the weight fragment is the A operand,
-// so that D[i = n][j = m] and every lane owns 4 CONSECUTIVE n of one output row m.
-template <bool SWAP>
+// One MFMA step, operands swapped: the weight fragment is the A operand, so that D[i = n][j = m] and every lane
+// owns 4 CONSECUTIVE n of one output row m.
 __device__ __forceinline__ f32x4 mma(const bf16x8& xa, const bf16x8& wb, const f32x4& c) {
-  if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wb, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xa, c, 0, 0, 0);
 }
 
 // Direct (register -> global) epilogue for the small kernel.
 template <int TM, int TN, int EPI, int ACT>
 __device__ __forceinline__ void epilogue_direct(const f32x4 (&acc)[TM][TN], const GemmArgs& p, int64_t mw, int nw, int lane) {
-  if constexpr (EPI != EPI_VT) {
+  {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nw + j * 16 + (lane >> 4) * 4;
@@ -105,35 +103,6 @@ __device__ __forceinline__ void epilogue_direct(const f32x4 (&acc)[TM][TN], cons
         }
       }
     }
-  } else {
-    bf16_t* vt = reinterpret_cast<bf16_t*>(p.out);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nw + j * 16 + (lane & 15);
-      const float bs = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int64_t m4 = mw + i * 16 + (lane >> 4) * 4;
-        if (m4 >= p.M) continue;
-        const int b = (int)(m4 / p.seq), s = (int)(m4 % p.seq);
-        const f32x4 v = acc[i][j];
-        if (s + 3 < p.seq && (p.seq & 3) == 0) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(v[r] + bs);
-          *reinterpret_cast<bf16x4*>(vt + ((int64_t)b * p.N + n) * p.seq_pad + s) = o;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t m = m4 + r;
-            if (m < p.M) {
-              const int bb = (int)(m / p.seq), ss = (int)(m % p.seq);
-              vt[((int64_t)bb * p.N + n) * p.seq_pad + ss] = (bf16_t)(v[r] + bs);
-            }
-          }
-        }
-      }
-    }
   }
 }
 
@@ -144,7 +113,6 @@ template <int BM, int BN, int WM, int WN, int EPI, int ACT>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-  constexpr bool SWAP = (EPI != EPI_VT);
   constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, BUF = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -192,7 +160,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma<SWAP>(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma(af[i], bf[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -230,13 +198,12 @@ __device__ __forceinline__ void p8_stage(const GemmArgs& p, int s, int nk, int64
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
   _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
-    acc[ACC_I0 + i][ACC_J0 + jj] = mma<SWAP>(af[i][kk], BF[jj][kk], acc[ACC_I0 + i][ACC_J0 + jj]); \
+    acc[ACC_I0 + i][ACC_J0 + jj] = mma(af[i][kk], BF[jj][kk], acc[ACC_I0 + i][ACC_J0 + jj]); \
   __builtin_amdgcn_s_setprio(0);                                                                \
   __builtin_amdgcn_s_barrier();
 
 template <int EPI, int ACT>
 __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs p, int skew) {
-  constexpr bool SWAP = (EPI != EPI_VT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,9 +393,6 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st) {
     if (act == ACT_GELU) return launch_epi<EPI_BF16, ACT_GELU>(p, st, epi, act);
   } else if (epi == EPI_F32) {
     if (act == ACT_NONE) return launch_epi<EPI_F32, ACT_NONE>(p, st, epi, act);
-  } else if (epi == EPI_VT) {
-    CACO_REQUIRE(p.seq > 0 && p.seq_pad >= p.seq, "gemm_bf16: bad seq / seq_pad for the transposed store");
-    if (act == ACT_NONE) return launch_epi<EPI_VT, ACT_NONE>(p, st, epi, act);
   }
   set_error("gemm_bf16: unsupported epilogue %d / activation %d", epi, act);
   return CACO_ERR_INVALID;

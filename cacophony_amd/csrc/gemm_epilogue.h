@@ -17,8 +17,8 @@ __device__ __forceinline__ float epi_act(float x) {
   return x;
 }
 
-// acc[i][j]: block (rows mw + 16 i, cols nw + 16 j).  EPI_BF16 / EPI_F32 use the swapped MFMA form
-// (lane = (m = lane & 15, 4 consecutive n at (lane >> 4) * 4)); EPI_VT the direct form (lane = (n, 4 consecutive m)).
+// acc[i][j]: block (rows mw + 16 i, cols nw + 16 j), swapped MFMA form: lane = (m = lane & 15, 4 consecutive n at
+// (lane >> 4) * 4).
 template <int EPI, int ACT>
 __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], const GemmArgs& p, int64_t mw, int nw,
                                                      int lane, char* sc) {
@@ -67,42 +67,6 @@ __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], c
           const int64_t o = m * p.ldc + nw + c4 * 4;
           if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-        }
-      }
-    }
-  } else {
-    // transposed per-clip store vt[b][n][s] <- (m = b*S + s, n)
-    constexpr int PITCH = 256;                    // 128 bf16; 8-byte chunk q of row r lives at chunk q ^ (r & 15)
-    bf16_t* vt = reinterpret_cast<bf16_t*>(p.out);
-    const bool vec = (p.seq & 3) == 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float bs = p.bias ? p.bias[nw + j * 16 + lm] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[i][j][r] + bs);
-        *reinterpret_cast<bf16x4*>(sc + lm * PITCH + (((i * 4 + lg) ^ lm) << 3)) = o;
-      }
-#pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {            // 2 n-rows x 256 B (128 tokens) per store instruction
-        const int nl = tt * 2 + (lane >> 5), tk = (lane & 31) * 4;
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(sc + nl * PITCH + (((lane & 31) ^ nl) << 3));
-        const int64_t m = mw + tk;
-        const int64_t nrow = (int64_t)(nw + j * 16 + nl);
-        if (m < p.M) {
-          const int b = (int)(m / p.seq), s = (int)(m % p.seq);
-          if (vec && m + 3 < p.M) {
-            *reinterpret_cast<bf16x4*>(vt + ((int64_t)b * p.N + nrow) * p.seq_pad + s) = v;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (m + r < p.M) {
-                const int bb = (int)((m + r) / p.seq), ss = (int)((m + r) % p.seq);
-                vt[((int64_t)bb * p.N + nrow) * p.seq_pad + ss] = v[r];
-              }
-          }
         }
       }
     }

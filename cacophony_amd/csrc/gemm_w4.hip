@@ -370,7 +370,7 @@ int launch_w4(const GemmArgs& p, hipStream_t st) {
 }  // namespace
 
 bool gemm_bf16_w4_ok(const GemmArgs& p, int epi) {
-  return p.N % 256 == 0 && p.K % WBK == 0 && p.K >= WBK && epi != EPI_VT &&
+  return p.N % 256 == 0 && p.K % WBK == 0 && p.K >= WBK &&
          (int64_t)256 * (p.lda ? p.lda : p.K) * 2 < 0x7fffffff && (int64_t)256 * (p.ldw ? p.ldw : p.K) * 2 < 0x7fffffff;
 }
 

@@ -68,7 +68,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <int EPI, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_x_kernel(GemmArgs p) {
-  constexpr bool SWAP = (EPI != EPI_VT);   // SWAP: D[i = n][j = m], lane owns 4 consecutive n of one row m
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,10 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_x_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < 4; ++j)    // operands swapped: D[i = n][j = m], a lane owns 4 consecutive n of one row m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   }
   __builtin_amdgcn_s_barrier();                   // the ring is idle: reuse it as per-wave transpose slabs
@@ -147,8 +144,6 @@ int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st) {
     if (act == ACT_GELU) return launch_x<EPI_BF16, ACT_GELU>(p, st);
   } else if (epi == EPI_F32 && act == ACT_NONE) {
     return launch_x<EPI_F32, ACT_NONE>(p, st);
-  } else if (epi == EPI_VT && act == ACT_NONE) {
-    return launch_x<EPI_VT, ACT_NONE>(p, st);
   }
   set_error("gemm_bf16_x: unsupported epilogue %d / activation %d", epi, act);
   return CACO_ERR_INVALID;

@@ -5,7 +5,7 @@
 
 namespace caco {
 
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_VT = 2 };
+enum { EPI_BF16 = 0, EPI_F32 = 1 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2 };
 
 struct GemmArgs {
@@ -13,10 +13,9 @@ struct GemmArgs {
   const bf16_t* W;      // [N, K]
   const float* bias;    // [N] or null
   const float* resid;   // EPI_F32: [M, ldc] fp32 or null (may alias out)
-  void* out;            // EPI_BF16: bf16 [M, ldc]; EPI_F32: fp32 [M, ldc]; EPI_VT: bf16 [M/seq, N, seq_pad]
+  void* out;            // EPI_BF16: bf16 [M, ldc]; EPI_F32: fp32 [M, ldc]
   int64_t M;
   int N, K, ldc;
-  int seq, seq_pad;     // EPI_VT only
   int lda, ldw;         // row strides of A / W in elements; 0 = K (dense)
   int ngroup;           // gemm_x: n-tiles per L2 group (0 = all)
 };
@@ -46,9 +45,9 @@ int cast_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st);
 int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq, int dst_off, int dim, hipStream_t st);
 
 // attention.hip
-int attn_seq_pad(int seq);
-int attention(const bf16_t* qk, const bf16_t* vt, const float* key_mask, int batch, int seq, int heads, int head_dim,
-              int causal, bf16_t* out, hipStream_t st);
+// qkv: bf16 [batch*seq, ld], Q at column 0, K at k_off, V at v_off (head h = columns h*head_dim.. of each)
+int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
+              int head_dim, int causal, bf16_t* out, hipStream_t st);
 
 // pool.hip: learned-query attention pooling over kv[b, s, 0:H | H:2H] (bf16) -> out fp32 [B, H]
 int attn_pool(const bf16_t* kv, const float* query, const float* mask, int batch, int seq, int hidden, int heads,

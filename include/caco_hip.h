@@ -145,16 +145,12 @@ int caco_op_gemm_bf16_f32out(const void* a_dev, const void* w_dev, const float* 
 /* LayerNorm over the last axis of fp32 x[rows, dim]; out_f32_dev / out_bf16_dev may each be NULL. */
 int caco_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, int64_t rows, int32_t dim,
                       float eps, float* out_f32_dev, void* out_bf16_dev, void* stream);
-/* Fused softmax(QK^T * scale + mask) V for the encoder layouts: qk_dev bf16 [B*S, 2*H] (Q | K),
- * vt_dev bf16 [B, H, S_pad] (V transposed, S_pad = caco_attn_seq_pad(S)), key_mask_dev fp32 [B,S] or NULL,
- * out_dev bf16 [B*S, H].  head_dim in {64, 96}. */
-int32_t caco_attn_seq_pad(int32_t seq);
-int caco_op_attention(const void* qk_dev, const void* vt_dev, const float* key_mask_dev, int32_t batch, int32_t seq,
-                      int32_t heads, int32_t head_dim, int32_t causal, void* out_dev, void* stream);
-/* bf16 GEMM whose output is written transposed per clip: vt[b, n, s] = (A x W^T + bias)[b*S + s, n] */
-int caco_op_gemm_bf16_vt(const void* a_dev, const void* w_dev, const float* bias_dev, int32_t batch, int32_t seq,
-                         int32_t N, int32_t K, void* vt_dev, void* stream);
-
+/* Fused softmax(QK^T * scale + mask) V for the encoder layout: qkv_dev bf16 [B*S, ld] with Q at column 0, K at
+ * column k_off, V at column v_off (head h = columns h*head_dim.. of each), key_mask_dev fp32 [B,S] or NULL,
+ * out_dev bf16 [B*S, heads*head_dim].  head_dim in {64, 96}; ld, k_off, v_off multiples of 8. */
+int caco_op_attention(const void* qkv_dev, int32_t ld, int32_t k_off, int32_t v_off, const float* key_mask_dev,
+                      int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out_dev,
+                      void* stream);
 #ifdef __cplusplus
 }
 #endif

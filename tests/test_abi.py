@@ -37,7 +37,6 @@ def test_host_side_helpers_without_gpu():
     lib = _lib.load()
     assert lib.caco_mel_num_frames(160000) == 1000          # eval_caco_torch.py:66-72
     assert lib.caco_mel_num_frames(12345) == 78
-    assert lib.caco_attn_seq_pad(500) == 512 and lib.caco_attn_seq_pad(32) == 64
     assert lib.caco_set_gemm_tile(0) in (128, 256)
 
 

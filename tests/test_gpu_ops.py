@@ -83,25 +83,6 @@ def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 1256, 2256, 4256])
-@pytest.mark.parametrize("B,S", [(3, 500), (5, 32), (2, 498), (1, 1500)])
-def test_gemm_bf16_transposed_v_store(lib, tile, B, S):
-    lib.caco_set_gemm_tile(tile)
-    N, K = 768, 768
-    a = _rand((B * S, K), 8).bfloat16()
-    w = _rand((N, K), 9, 1.0 / math.sqrt(K)).bfloat16()
-    bias = _rand((N,), 10)
-    sp = lib.caco_attn_seq_pad(S)
-    assert sp % 64 == 0 and sp >= S
-    vt = torch.zeros(B, N, sp, dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.caco_op_gemm_bf16_vt(_p(a), _p(w), _p(bias), B, S, N, K, _p(vt), _st()))
-    ref = (a.float() @ w.float().T + bias).reshape(B, S, N).transpose(1, 2)
-    torch.cuda.synchronize()
-    assert (vt[:, :, :S].float() - ref).abs().max().item() < 0.05
-    assert (vt[:, :, S:] == 0).all()
-    lib.caco_set_gemm_tile(256)
-
-
 def test_gemm_rejects_bad_shapes(lib):
     a = torch.zeros(64, 100, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(ValueError):
@@ -147,18 +128,16 @@ def test_attention(lib, B, S, heads, hd, causal, valid):
     mask = torch.zeros(B, S, device=DEV)
     for i, n in enumerate(valid):
         mask[i, :n] = 1
-    sp = lib.caco_attn_seq_pad(S)
-    vt = torch.zeros(B, H, sp, dtype=torch.bfloat16, device=DEV)
-    vt[:, :, :S] = v.transpose(1, 2)
+    qkv = torch.cat([qk, v], -1).contiguous()          # row = Q | K | V, the fused projection's layout
     out = torch.full((B, S, H), float("nan"), dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), _p(mask), B, S, heads, hd, causal, _p(out), _st()))
+    _lib.check(lib.caco_op_attention(_p(qkv), 3 * H, H, 2 * H, _p(mask), B, S, heads, hd, causal, _p(out), _st()))
     ref = _attention_ref(qk, v, mask, heads, hd, bool(causal))
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     err = (out.float() - ref).abs().max().item()
     assert err < 0.03, f"max err {err}"
     # no mask pointer == all keys kept
-    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), None, B, S, heads, hd, causal, _p(out), _st()))
+    _lib.check(lib.caco_op_attention(_p(qkv), 3 * H, H, 2 * H, None, B, S, heads, hd, causal, _p(out), _st()))
     ref = _attention_ref(qk, v, None, heads, hd, bool(causal))
     torch.cuda.synchronize()
     assert (out.float() - ref).abs().max().item() < 0.03
@@ -173,10 +152,9 @@ def test_attention_forced_rescale(lib):
     qk[0, 450, H:H + hd] = 4.0        # key 450 of head 0 aligned with query 7
     qk = qk.bfloat16()
     v = _rand((B, S, H), 31).bfloat16()
-    vt = torch.zeros(B, H, lib.caco_attn_seq_pad(S), dtype=torch.bfloat16, device=DEV)
-    vt[:, :, :S] = v.transpose(1, 2)
+    qkv = torch.cat([qk, v], -1).contiguous()
     out = torch.empty(B, S, H, dtype=torch.bfloat16, device=DEV)
-    _lib.check(lib.caco_op_attention(_p(qk), _p(vt), None, B, S, heads, hd, 0, _p(out), _st()))
+    _lib.check(lib.caco_op_attention(_p(qkv), 3 * H, H, 2 * H, None, B, S, heads, hd, 0, _p(out), _st()))
     ref = _attention_ref(qk, v, None, heads, hd, False)
     torch.cuda.synchronize()
     assert (out.float() - ref).abs().max().item() < 0.03

@@ -12,9 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cacophony_amd import _lib  # noqa: E402
 
 SHAPES = {  # name: (M, N, K, kind, act)
-    "qk": (128000, 1536, 768, "bf16", 0), "v": (128000, 768, 768, "vt", 0), "out": (128000, 768, 768, "f32r", 0),
+    "qkv": (128000, 2304, 768, "bf16", 0), "out": (128000, 768, 768, "f32r", 0),
     "fc1": (128000, 3072, 768, "bf16", 1), "fc2": (128000, 768, 3072, "f32r", 0), "embed": (128000, 768, 256, "f32", 0),
-    "t_qk": (8192, 1536, 768, "bf16", 0), "t_fc1": (8192, 3072, 768, "bf16", 2), "t_fc2": (8192, 768, 3072, "f32r", 0),
+    "t_qkv": (8192, 2304, 768, "bf16", 0), "t_out": (8192, 768, 768, "f32r", 0), "t_fc1": (8192, 3072, 768, "bf16", 2), "t_fc2": (8192, 768, 3072, "f32r", 0),
 }
 
 
@@ -38,10 +38,6 @@ def main():
         if kind == "bf16":
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             run = lambda: lib.caco_op_gemm_bf16(p(A), p(W), p(bias), M, N, K, act, p(out), st)
-        elif kind == "vt":
-            S = 500
-            out = torch.zeros(M // S, N, 512, dtype=torch.bfloat16, device=dev)
-            run = lambda: lib.caco_op_gemm_bf16_vt(p(A), p(W), p(bias), M // S, S, N, K, p(out), st)
         else:
             out = torch.randn(M, N, device=dev)
             res = out if kind == "f32r" else None

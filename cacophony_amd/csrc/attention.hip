@@ -11,9 +11,11 @@
 // from LDS with the gfx950 hardware transpose read (ds_read_b64_tr_b16), so no V^T copy is ever written.
 //
 // Work split: one workgroup = NW waves = 32*NW query rows of one (clip, head); each wave owns 32 query rows and
-// the full head dimension.  K / V tiles of 64 keys are register-staged into LDS (K rows padded by 16 B, V rows
-// unpadded: both conflict-free for their read patterns), double-buffered, with the next tile's global loads
-// issued before the current tile's MFMAs (issue-early / write-late).
+// the full head dimension.  K / V tiles of 64 keys go HBM/L2 -> LDS by 16-byte DMA (buffer_load ... lds: no staging
+// registers, no ds_write), double-buffered, the next tile's DMA issued before the current tile's MFMAs.  The LDS
+// images are lane-linear (a DMA constraint), i.e. unpadded 2*HD-byte rows: the V image is conflict-free as it is for
+// the transpose reads; the K image is made conflict-free for ds_read_b128 by XOR-ing the low two bits of the 16-byte
+// chunk index with (key >> 2) & 3 on the SOURCE address and again on the read address.
 //
 // Math per 64-key tile, all on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
 //   S^T[key, q] = K Q^T      (operands swapped so that every lane owns ONE query column: the row-wise softmax is
@@ -34,7 +36,8 @@ namespace caco {
 namespace {
 
 constexpr int KT = 64;         // keys per tile
-constexpr int VP = 192;        // V row pitch in bytes (4 consecutive keys' 64-byte segments tile the 256-byte bank row)
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -42,6 +45,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 __device__ __forceinline__ int key_perm(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // 8 consecutive keys x one head-dim column per lane = A operand of O^T += V^T P^T, from the key-major V tile
+template <int VP>
 __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * VP));
@@ -50,17 +54,21 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// (the body lives in a __device__ function: the buffer-descriptor builtins it uses are not visible to the host pass)
 template <int HD, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
-                                                            const float* __restrict__ key_mask, int S, int heads,
-                                                            bf16_t* __restrict__ out, float scale_log2) {
+__device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
+                                               const float* __restrict__ key_mask, int S, int heads,
+                                               bf16_t* __restrict__ out, float scale_log2) {
   constexpr int NT = NW * 64, QB = NW * 32;
-  constexpr int KP = HD * 2 + 16;              // K row pitch (208 / 144 bytes)
+  constexpr int RP = HD * 2;                   // K and V row pitch in LDS = the unpadded row (192 / 128 bytes)
+  constexpr int VP = RP;
   constexpr int KCH = HD / 8;                  // 16-byte chunks per K / V row
-  constexpr int NCH = (KT * KCH + NT - 1) / NT;  // chunks per thread per tile (the last round may be partial)
+  constexpr int NPC = KT * RP / 1024;          // 1 KiB DMA pieces per operand tile (12 / 8)
+  constexpr int PPW = NPC / NW;                // pieces per wave
+  static_assert(NPC % NW == 0, "pieces must divide evenly over the waves");
   constexpr int KS = HD / 16;                  // MFMA k-steps over the head dim
   constexpr int DT = HD / 32;                  // 32-row output tiles over the head dim
-  constexpr int K_BYTES = KT * KP, V_BYTES = KT * VP, BUF = K_BYTES + V_BYTES + KT * 4 + 16;
+  constexpr int K_BYTES = KT * RP, V_BYTES = KT * RP, BUF = K_BYTES + V_BYTES + KT * 4 + 16;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, l31 = lane & 31;
@@ -69,8 +77,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
   const int H = heads * HD;
   const int64_t row_base = (int64_t)b * S;
   const bf16_t* q_base = qkv + row_base * ld + h * HD;
-  const bf16_t* k_base = q_base + k_off;
-  const bf16_t* v_base = q_base + v_off;
 
   const int q0 = qb * QB + wave * 32;
   const int q_row = q0 + l31;
@@ -90,40 +96,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
     ntiles = min(ntiles, last_q / KT + 1);
   }
 
-  bf16x8 kreg[NCH], vreg[NCH];
-  float breg = 0.f;
-  auto load_tile = [&](int t) {
-    const int key0 = t * KT;
+  // DMA geometry: piece pc of a tile covers LDS bytes [pc*1024, +1024) = linear 16-byte chunks pc*64 + lane.
+  // chunk L -> row L / KCH, chunk position L % KCH; the K source chunk is un-swizzled from the position.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)q_base, 0, 0x7fffffff, 0x00020000);
+  int d_row[PPW], d_kcol[PPW], d_vcol[PPW];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int id = tid + i * NT;
-      if (KT * KCH % NT == 0 || id < KT * KCH) {
-        const int r = id / KCH, c = id % KCH;
-        const int64_t key = min(key0 + r, S - 1);
-        kreg[i] = *reinterpret_cast<const bf16x8*>(k_base + key * ld + c * 8);
-        vreg[i] = *reinterpret_cast<const bf16x8*>(v_base + key * ld + c * 8);
-      }
+  for (int i = 0; i < PPW; ++i) {
+    const int L = (wave + i * NW) * 64 + lane;
+    const int r = L / KCH, pos = L % KCH;
+    d_row[i] = r;
+    d_kcol[i] = (k_off + (((pos & ~3) | ((pos & 3) ^ ((r >> 2) & 3))) * 8)) * 2;
+    d_vcol[i] = (v_off + pos * 8) * 2;
+  }
+  float mreg = 1.f;
+  auto issue_tile = [&](int t, int buf) {
+    const int key0 = t * KT;
+    char* kb = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int rowoff = min(key0 + d_row[i], S - 1) * ld * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + (wave + i * NW) * 1024), 16, rowoff + d_kcol[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + K_BYTES + (wave + i * NW) * 1024), 16, rowoff + d_vcol[i], 0, 0, 0);
     }
+    // wave 0 fetches the tile's key mask; the value is only consumed in finish_tile, so that no wait on it (it would
+    // also drain the DMA just issued) lands here
     if (tid < KT) {
       const int key = key0 + tid;
-      const bool keep = key < S && (key_mask == nullptr || key_mask[row_base + key] != 0.f);
-      breg = keep ? 0.f : -INFINITY;
+      mreg = (key < S) ? (key_mask ? key_mask[row_base + key] : 1.f) : 0.f;
     }
   };
-  auto store_tile = [&](int buf) {
-    char* kb = smem + buf * BUF;
-    char* vb = kb + K_BYTES;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int id = tid + i * NT;
-      if (KT * KCH % NT == 0 || id < KT * KCH) {
-        const int r = id / KCH, c = id % KCH;
-        *reinterpret_cast<bf16x8*>(kb + r * KP + c * 16) = kreg[i];
-        *reinterpret_cast<bf16x8*>(vb + r * VP + c * 16) = vreg[i];
-      }
-    }
-    if (tid < KT) {      // wave 0: per-key additive mask + "this tile has a masked key" flag
-      float* bias = reinterpret_cast<float*>(vb + V_BYTES);
+  auto finish_tile = [&](int buf) {      // wave 0: per-key additive mask + "this tile has a masked key" flag
+    if (tid < KT) {
+      float* bias = reinterpret_cast<float*>(smem + buf * BUF + K_BYTES + V_BYTES);
+      const float breg = mreg != 0.f ? 0.f : -INFINITY;
       bias[tid] = breg;
       const unsigned long long any = __ballot(breg != 0.f);
       if (tid == 0) reinterpret_cast<int*>(bias + KT)[0] = any != 0ull;
@@ -141,26 +146,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
   // lane >> 5 the 8-key half, (lane & 15) >> 2 the key within a 4-key block, lane & 3 the 4-column piece
   const int v_lane = (8 * hf + ((lane & 15) >> 2)) * VP + ((((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2);
 
-  load_tile(0);
-  store_tile(0);
+  issue_tile(0, 0);
+  finish_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) load_tile(t + 1);
+    if (t + 1 < ntiles) issue_tile(t + 1, (t + 1) & 1);
     if (wave_active) {
       const char* kb = smem + (t & 1) * BUF;
       const char* vb = kb + K_BYTES;
       const float* bias = reinterpret_cast<const float*>(vb + V_BYTES);
       f32x16 s[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      // the two 32-key chains are interleaved so that no MFMA waits on the one issued right before it
+      const int kx = (key_perm(l31) >> 2) & 3;          // same for both 32-key halves (32 >> 2 is a multiple of 4)
+      const char* kr = kb + key_perm(l31) * RP;
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = ks * 2 + hf;       // logical 16-byte chunk; stored at (c & ~3) | ((c & 3) ^ kx)
+        const int coff = ((c & ~3) | ((c & 3) ^ kx)) << 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
-        const char* kr = kb + (st * 32 + key_perm(l31)) * KP + hf * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + ks * 32);
-          s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[st], 0, 0, 0);
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + st * 32 * RP + coff);
+          s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[st], 0, 0, 0);   // C = 0 literal
         }
       }
       // masks (only for tiles that have any): s[st][g*8 + e] is key t*64 + st*32 + 16*g + 8*hf + e
@@ -191,18 +200,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
       const float m_new = fmaxf(m_run, m_tile);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float neg = -m_use * scale_log2;
-      float psum = 0.f;
+      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 work on register pairs) and four independent partial sums
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 sc2 = {scale_log2, scale_log2}, neg2 = {neg, neg};
+      f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
       bf16x8 pf[4];
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[st][g * 8 + e], scale_log2, neg));
-            psum += p;
-            pf[st * 2 + g][e] = (bf16_t)p;
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 sv = {s[st][g * 8 + e], s[st][g * 8 + e + 1]};
+            const f32x2 x = __builtin_elementwise_fma(sv, sc2, neg2);
+            const f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            ps2[(e >> 1) & 1] += p;
+            pf[st * 2 + g][e] = (bf16_t)p[0];
+            pf[st * 2 + g][e + 1] = (bf16_t)p[1];
           }
+      const float psum = (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
       if (__ballot(m_new > m_run) != 0ull) {       // some row's max moved: rescale this wave's running state
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2);   // m_run = -inf -> 0
         l_run *= alpha;
@@ -215,16 +231,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
       l_run += psum;
       // O^T += V^T P^T
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const char* vr = vb + v_lane + dt * 64;
+      for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-          const bf16x8 vf = v_frag_tr(vr + sp * 16 * VP);
+        for (int dt = 0; dt < DT; ++dt) {      // DT independent accumulator chains, interleaved
+          const bf16x8 vf = v_frag_tr<VP>(vb + v_lane + dt * 64 + sp * 16 * VP);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], o[dt], 0, 0, 0);
         }
-      }
     }
-    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+    if (t + 1 < ntiles) finish_tile((t + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile t+1 have landed
     __syncthreads();
   }
 
@@ -243,6 +258,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_kernel(const bf16_t* __r
         *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
       }
   }
+}
+
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void attention_kernel(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
+                                                               const float* __restrict__ key_mask, int S, int heads,
+                                                               bf16_t* __restrict__ out, float scale_log2) {
+  attention_body<HD, CAUSAL, NW>(qkv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2);
 }
 
 }  // namespace

@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--audio-streams", type=int, default=1, help="streams the clip batch is split over (1 = one audio stream; the text tower always runs on its own)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,8 +145,9 @@ def main():
     sim_out = torch.empty(B_PER_GPU, world * B_PER_GPU, dtype=torch.float32, device=device)
 
     def step():
-        ea = model.encode_audio(wav, SEQ)
-        et = model.encode_text(ids, mask)
+        # text tower on a side stream, clip batch split over two streams (one workspace per tower and stream inside
+        # the library): memory-bound kernels of one stream overlap the MFMA-bound GEMMs of another
+        ea, et = model.encode_pairs(wav, ids, mask, SEQ, audio_streams=args.audio_streams)
         _, t_all = gather_embedding_banks(ea, et)
         return similarity(ea, t_all, 1.0, out=sim_out)
 

@@ -114,9 +114,10 @@ struct caco_model {
   Lin tpool_kv;
   float *text_proj_w = nullptr, *text_proj_b = nullptr;
   float logit_scale = 0.f;
-  // workspace arena
-  char* ws = nullptr;
-  size_t ws_bytes = 0;
+  // workspace arenas, one per (tower, stream): forwards enqueued on DIFFERENT streams (audio next to text, or two
+  // half batches) never share scratch memory and may overlap on the GPU; calls on one stream reuse one arena
+  struct WsBuf { char* p = nullptr; size_t bytes = 0; };
+  std::map<std::pair<int, void*>, WsBuf> arenas;
 };
 
 namespace caco {
@@ -289,27 +290,28 @@ int build_weights(caco_model* m) {
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
+enum { WS_AUDIO = 0, WS_TEXT = 1, WS_FRONTEND = 2 };
 struct Arena {
-  caco_model* m;
+  caco_model::WsBuf* w;
   size_t off = 0;
-  explicit Arena(caco_model* mm) : m(mm) {}
+  Arena(caco_model* mm, int tower, hipStream_t st) : w(&mm->arenas[std::make_pair(tower, (void*)st)]) {}
   size_t reserve(size_t bytes) {
     const size_t o = off;
     off += (bytes + 255) & ~(size_t)255;
     return o;
   }
   int commit(hipStream_t st) {
-    if (off <= m->ws_bytes) return CACO_OK;
-    CACO_HIP(hipStreamSynchronize(st));       // earlier work may still be using the old arena
-    if (m->ws) CACO_HIP(hipFree(m->ws));
-    m->ws = nullptr;
-    m->ws_bytes = 0;
-    CACO_HIP(hipMalloc(reinterpret_cast<void**>(&m->ws), off));
-    m->ws_bytes = off;
+    if (off <= w->bytes) return CACO_OK;
+    CACO_HIP(hipStreamSynchronize(st));       // earlier work on this stream may still be using the old arena
+    if (w->p) CACO_HIP(hipFree(w->p));
+    w->p = nullptr;
+    w->bytes = 0;
+    CACO_HIP(hipMalloc(reinterpret_cast<void**>(&w->p), off));
+    w->bytes = off;
     return CACO_OK;
   }
   template <typename T>
-  T* at(size_t o) const { return reinterpret_cast<T*>(m->ws + o); }
+  T* at(size_t o) const { return reinterpret_cast<T*>(w->p + o); }
 };
 
 int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st) {
@@ -430,7 +432,7 @@ int caco_create(const caco_config* cfg, caco_model** out) {
 void caco_destroy(caco_model* m) {
   if (!m) return;
   for (void* p : m->owned) (void)hipFree(p);
-  if (m->ws) (void)hipFree(m->ws);
+  for (auto& kv : m->arenas) if (kv.second.p) (void)hipFree(kv.second.p);
   delete m;
 }
 
@@ -476,7 +478,11 @@ int caco_set_logit_scale(caco_model* m, float v) {
   return CACO_OK;
 }
 float caco_get_logit_scale(const caco_model* m) { return m ? m->logit_scale : 0.f; }
-int64_t caco_workspace_bytes(const caco_model* m) { return m ? (int64_t)m->ws_bytes : 0; }
+int64_t caco_workspace_bytes(const caco_model* m) {
+  int64_t n = 0;
+  if (m) for (auto& kv : m->arenas) n += (int64_t)kv.second.bytes;
+  return n;
+}
 int32_t caco_set_gemm_tile(int32_t tile) { return set_gemm_tile_config(tile); }
 
 int caco_profile_enable(int32_t on) {
@@ -538,7 +544,7 @@ int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const 
   const caco_config& c = m->cfg;
   const int H = c.audio_hidden, P = c.patch_size;
   const int64_t M = (int64_t)batch * seq;
-  Arena A(m);
+  Arena A(m, WS_AUDIO, st);
   AudioWs w;
   w.plan(A, M, batch, seq, H, c.audio_intermediate);
   const size_t o_pb = A.reserve((size_t)M * P * 2);
@@ -579,7 +585,7 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   hipStream_t st = (hipStream_t)stream;
   const int H = c.text_hidden, I = c.text_intermediate;
   const int64_t M = (int64_t)batch * seq;
-  Arena A(m);
+  Arena A(m, WS_TEXT, st);
   const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
   const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2);
   const size_t o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
@@ -627,21 +633,13 @@ int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_
   CACO_TRY(check_audio_shapes(m, batch, max_patches));
   CACO_REQUIRE(wav && emb && n_samples > 0, "caco_encode_audio: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  // front-end outputs live in their own allocation so that the forward's arena growth cannot move them
-  static thread_local char* fe = nullptr;
-  static thread_local size_t fe_bytes = 0;
+  // front-end outputs live in their own arena so that the forward's arena growth cannot move them
   const size_t n_tok = (size_t)batch * max_patches;
-  const size_t need = n_tok * 256 * 2 + 3 * n_tok * 4 + 1024;
-  if (need > fe_bytes) {
-    CACO_HIP(hipStreamSynchronize(st));
-    if (fe) CACO_HIP(hipFree(fe));
-    fe = nullptr;
-    fe_bytes = 0;
-    CACO_HIP(hipMalloc(reinterpret_cast<void**>(&fe), need));
-    fe_bytes = need;
-  }
-  bf16_t* patches = reinterpret_cast<bf16_t*>(fe);
-  float* tinds = reinterpret_cast<float*>(fe + ((n_tok * 256 * 2 + 255) & ~(size_t)255));
+  Arena F(m, WS_FRONTEND, st);
+  const size_t o_p = F.reserve(n_tok * 256 * 2), o_i = F.reserve(3 * n_tok * 4);
+  CACO_TRY(F.commit(st));
+  bf16_t* patches = F.at<bf16_t>(o_p);
+  float* tinds = F.at<float>(o_i);
   float* finds = tinds + n_tok;
   float* mask = finds + n_tok;
   CACO_STAGE("mel.patches", mel_frontend(wav, batch, n_samples, max_patches, 0.2f, 0.9f, patches, MEL_PATCH_BF16, tinds, finds, mask, st));
@@ -670,7 +668,7 @@ int caco_mae_forward(caco_model* m, const void* patches, int32_t dtype, const fl
   const caco_config& c = m->cfg;
   const int H = c.audio_hidden, P = c.patch_size, S = nv + nr;
   const int64_t Mv = (int64_t)batch * nv, Mr = (int64_t)batch * nr, M = (int64_t)batch * S;
-  Arena A(m);
+  Arena A(m, WS_AUDIO, st);
   AudioWs w;
   w.plan(A, M, batch, S, H, c.audio_intermediate);      // sized for the decoder (S >= V); the encoder reuses it
   const size_t o_pb = A.reserve((size_t)Mv * P * 2), o_tmp = A.reserve((size_t)M * H * 4);

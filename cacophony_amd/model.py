@@ -205,7 +205,7 @@ class CACO(_HipModel):
     __call__ = forward
 
     # ---- convenience wrappers named in BASELINE.json north_star ---------------------------------
-    def encode_audio(self, wav, max_patches: Optional[int] = None) -> Tensor:
+    def encode_audio(self, wav, max_patches: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
         """wav fp32 [B, n_samples] (16 kHz) -> L2-normalised audio embeddings [B, projection_size].
         = prepare_audio_batch (eval_caco_torch.py:181-206) + get_audio_embedding(normalize=True), all on device."""
         wav = _dev_tensor(wav, torch.float32, self.device, "wav")
@@ -214,7 +214,9 @@ class CACO(_HipModel):
         B, n = wav.shape
         if max_patches is None:
             max_patches = max(8, n * 8 // 160 // 16)    # patches_seq_len rule, eval_caco_torch.py:573,607-612
-        emb = torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
+        emb = out if out is not None else torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
+        if tuple(emb.shape) != (B, self.caco_config.projection_size) or emb.dtype != torch.float32 or not emb.is_contiguous():
+            raise ValueError("encode_audio: `out` must be a contiguous fp32 [B, projection_size] tensor")
         with torch.cuda.device(self.device):
             _lib.check(self._lib.caco_encode_audio(self._handle, _ptr(wav), B, n, int(max_patches), _ptr(emb), _stream()),
                        "encode_audio")
@@ -222,6 +224,46 @@ class CACO(_HipModel):
 
     def encode_text(self, text_input_ids, text_mask) -> Tensor:
         return self.get_text_embedding(text_input_ids, text_mask, return_hidden_state=False, normalize=True)
+
+    def encode_pairs(self, wav, text_input_ids, text_mask, max_patches: Optional[int] = None,
+                     audio_streams: int = 1) -> Tuple[Tensor, Tensor]:
+        """Embed clips and captions CONCURRENTLY: the text tower runs on a side stream next to the audio tower, and
+        the clip batch is split over `audio_streams` streams.  The library keeps one workspace per (tower, stream),
+        so the launches of different streams interleave on the GPU: one stream's memory-bound kernels (LayerNorm,
+        attention, GEMM epilogues) fill the HBM time another stream's MFMA-bound GEMM leaves idle.  Same results
+        as encode_audio + encode_text.  Returns (audio_emb [B,P], text_emb [Bt,P]), valid on the current stream."""
+        wav = _dev_tensor(wav, torch.float32, self.device, "wav")
+        if wav.dim() == 1:
+            wav = wav[None]
+        B = wav.shape[0]
+        n_split = max(1, min(int(audio_streams), B))
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            pool = self._side_streams(n_split)            # n_split - 1 audio side streams + 1 text stream
+            ea = torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
+            bounds = [B * i // n_split for i in range(n_split + 1)]
+            for st in pool:
+                st.wait_stream(cur)
+            with torch.cuda.stream(pool[-1]):
+                et = self.encode_text(text_input_ids, text_mask)
+                et.record_stream(cur)
+            for i in range(n_split):
+                lo, hi = bounds[i], bounds[i + 1]
+                if i == 0:
+                    self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi])
+                else:
+                    with torch.cuda.stream(pool[i - 1]):
+                        self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi])
+            for st in pool:
+                cur.wait_stream(st)
+        return ea, et
+
+    def _side_streams(self, n_split: int):
+        key = max(1, n_split)
+        cache = self.__dict__.setdefault("_streams", {})
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=self.device) for _ in range(key)]
+        return cache[key]
 
 
 def similarity(a: Tensor, t: Tensor, scale: float = 1.0, out: Optional[Tensor] = None) -> Tensor:

@@ -14,8 +14,10 @@
  *     synchronising unless stated.
  *   - every function returns CACO_OK (0) or a negative status; caco_last_error() gives the
  *     message of the calling thread's last failure.  No C++ exceptions cross the boundary.
- *   - a caco_model owns its weights (bf16 GEMM operands, fp32 everything else) and one workspace
- *     arena grown on demand; it is NOT re-entrant: one in-flight forward per model.
+ *   - a caco_model owns its weights (bf16 GEMM operands, fp32 everything else) and one workspace arena per
+ *     (tower, stream), grown on demand: forwards enqueued on DIFFERENT streams (the text tower next to the audio
+ *     tower, or two half batches) share no scratch memory and may overlap on the GPU; calls that share a stream
+ *     are ordered by it.  Host-side the model is not thread safe: issue all calls from one thread.
  *   - row-major everywhere; Linear weights arrive in torch layout [out, in], fp32.
  */
 #ifndef CACO_HIP_H

@@ -176,6 +176,22 @@ def test_full_batch_properties(full_model):
     assert (sim.double() - ref).abs().max().item() < 1e-5
 
 
+def test_encode_pairs_multistream_equals_serial(full_model):
+    """encode_pairs (text on a side stream, clip batch over several streams, one workspace per tower and stream)
+    must reproduce the serial encode_audio / encode_text results exactly, repeatedly."""
+    B = 48
+    wav = synth.make_waveforms(8, start=200)
+    wav = np.concatenate([wav * (0.4 + 0.1 * i) for i in range(6)], 0)
+    ids, tmask = synth.make_captions(B, 32, start=300)
+    w = torch.from_numpy(wav).to(DEV)
+    ea = full_model.encode_audio(w)
+    et = full_model.encode_text(ids, tmask)
+    for n in (1, 2, 3, 2):
+        pa, pt = full_model.encode_pairs(w, ids, tmask, audio_streams=n)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, ea) and torch.equal(pt, et), f"audio_streams={n}"
+
+
 def test_api_error_behaviour(tiny_model):
     _, ab = _audio_batch(1)
     with pytest.raises(ValueError):

@@ -68,9 +68,10 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 }
 
 // Load cursors.  Each walks the K-tiles of this workgroup's output tiles in order, ahead of the compute cursor.
+template <int NWV>
 struct W4CurA {
   __amdgpu_buffer_rsrc_t r;
-  int voff[8];        // per-lane byte offsets of this wave's 8 row groups (rows clamped to the last valid row)
+  int voff[32 / NWV]; // per-lane byte offsets of this wave's row groups (rows clamped to the last valid row)
   int li, kt;
 };
 struct W4CurW {
@@ -79,17 +80,18 @@ struct W4CurW {
   int li, kt;
 };
 
-__device__ __forceinline__ void w4_setup_a(W4CurA& C, const GemmArgs& p, int t, int tiles_n, int lda, int wave, int lane) {
+template <int NWV>
+__device__ __forceinline__ void w4_setup_a(W4CurA<NWV>& C, const GemmArgs& p, int t, int tiles_n, int lda, int wave, int lane) {
 #ifdef W4_SAMEADDR
   t = 0;
 #endif
   const int64_t m0 = (int64_t)(t / tiles_n) * 256;
   C.r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + m0 * lda), 0, 0x7fffffff, 0x00020000);
-  const int r8 = wave * 8 + (lane >> 3);                         // row within a 32-row span
+  const int r8 = wave * 8 + (lane >> 3);                         // row within a span of NWV * 8 rows
   const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7); // (row >> 1) & 7 is the same for every span
   const int last = (int)min((int64_t)256, p.M - m0) - 1;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) C.voff[it] = min(it * 32 + r8, last) * lda * 2 + chunk * 16;
+  for (int it = 0; it < 32 / NWV; ++it) C.voff[it] = min(it * NWV * 8 + r8, last) * lda * 2 + chunk * 16;
 }
 __device__ __forceinline__ void w4_setup_w(W4CurW& C, const GemmArgs& p, int t, int tiles_n, int ldw, int wave, int lane) {
 #ifdef W4_SAMEADDR
@@ -102,16 +104,18 @@ __device__ __forceinline__ void w4_setup_w(W4CurW& C, const GemmArgs& p, int t, 
   C.voff = r8 * ldw * 2 + chunk * 16;
 }
 
-// piece `it` (0..7) of this wave's share of an operand K-tile: 8 rows x 128 B = one wave instruction
-__device__ __forceinline__ void w4_piece_a(const W4CurA& C, int it, char* slot, int wave) {
+// piece `it` of this wave's share of an operand K-tile: 8 rows x 128 B = one wave instruction
+template <int NWV>
+__device__ __forceinline__ void w4_piece_a(const W4CurA<NWV>& C, int it, char* slot, int wave) {
 #ifndef W4_NODMA
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * 4 + wave) * 1024), 16, C.voff[it], W4_KOFF(C.kt), 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * NWV + wave) * 1024), 16, C.voff[it], W4_KOFF(C.kt), 0, 0);
 #endif
 }
+template <int NWV>
 __device__ __forceinline__ void w4_piece_w(const W4CurW& C, int it, int ldw, char* slot, int wave) {
 #ifndef W4_NODMA
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * 4 + wave) * 1024), 16, C.voff,
-                                           W4_KOFF(C.kt) + it * 32 * ldw * 2, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * NWV + wave) * 1024), 16, C.voff,
+                                           W4_KOFF(C.kt) + it * NWV * 8 * ldw * 2, 0, 0);
 #endif
 }
 
@@ -217,8 +221,7 @@ __device__ __forceinline__ void w4_epilogue(const f32x16 (&acc)[4][4], const Gem
 }
 
 template <int EPI, int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // Past the last K-tile a cursor keeps re-reading its last tile (valid memory, into slots nobody reads any more):
   // the K-loop then has no branch around its DMA instructions and every step stays one basic block.
-  W4CurA CA;
+  W4CurA<4> CA;
   W4CurW CW;
   CA.li = CW.li = slot;
   CA.kt = CW.kt = 0;
@@ -264,16 +267,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // prologue: A(0) W(0) | A(1) W(1)[0..3]
 #pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_a(CA, it, smem + a_c, wave);
+  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_c, wave);
   advance_a();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_w(CW, it, ldw, smem + w_c, wave);
+  for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
   advance_w();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_a(CA, it, smem + a_1, wave);
+  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_1, wave);
   advance_a();
 #pragma unroll
-  for (int it = 0; it < 4; ++it) w4_piece_w(CW, it, ldw, smem + w_1, wave);
+  for (int it = 0; it < 4; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_1, wave);
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   bf16x8 x0[4], w0[4], x1[4], w1[4];
@@ -297,12 +300,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const char* xa = smem + a_c + x_off;
       const char* ww = smem + w_c + w_off;
       // ks0: compute (g,0), read (g,1); W(g+1) pieces 4..7
-      W4_STEP(x1, w1, xa, ww, 1, x0, w0, w4_piece_w(CW, 4 + q_, ldw, smem + w_1, wave))
+      W4_STEP(x1, w1, xa, ww, 1, x0, w0, w4_piece_w<4>(CW, 4 + q_, ldw, smem + w_1, wave))
       advance_w();
       // ks1: compute (g,1), read (g,2); A(g+2) pieces 0..3
-      W4_STEP(x0, w0, xa, ww, 2, x1, w1, w4_piece_a(CA, q_, smem + a_2, wave))
+      W4_STEP(x0, w0, xa, ww, 2, x1, w1, w4_piece_a<4>(CA, q_, smem + a_2, wave))
       // ks2: compute (g,2), read (g,3); A(g+2) pieces 4..7
-      W4_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a(CA, 4 + q_, smem + a_2, wave))
+      W4_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a<4>(CA, 4 + q_, smem + a_2, wave))
       advance_a();
       // A(g+1) and W(g+1) have landed (only A(g+2) may still be in flight); every wave is done reading A(g), W(g)
 #ifdef W4_NOLGKM
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // ks3: compute (g,3), read (g+1,0) (possibly of the next output tile); W(g+2) pieces 0..3 -> slot of W(g)
-      W4_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w(CW, q_, ldw, smem + w_c, wave))
+      W4_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w<4>(CW, q_, ldw, smem + w_c, wave))
       // rotate the rings
       { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
       { const int t_ = w_c; w_c = w_1; w_1 = t_; }
@@ -345,9 +348,265 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+
+// ================================================================================================
+// Eight-wave form: the same tile, rings, rotated K-loop and counted waits, but 2 (M) x 4 (N) waves of 128 x 64 each
+// = TWO waves per SIMD.  A wave that is stalled issuing an LDS-DMA instruction (~60 cycles each, measured), waiting
+// for a fragment or at the barrier leaves the SIMD's matrix pipe to its partner, which runs the same stream a
+// little out of phase; nothing forces the phase (no per-phase barriers).
+//   per wave and 16-deep step: 8 MFMAs, 6 fragment reads (x0 w0 x1 w1 x2 x3)
+//   per wave and K-tile: 4 A pieces (ks1, ks2) + 4 W pieces (ks3); s_waitcnt vmcnt(4) leaves A(g+2) in flight at the barrier
+// ================================================================================================
+#define W8_STEP(XN, WN, XA, WW, KS, XC, WC, DMA0, DMA1, DMA2, DMA3)                               \
+  if (W4_DO_READS) {                                                                             \
+    XN[0] = w4_frag(XA, 0 * 32 + frow, (KS) * 2 + fhalf);                                        \
+    WN[0] = w4_frag(WW, 0 * 32 + frow, (KS) * 2 + fhalf);                                        \
+  }                                                                                              \
+  DMA0;                                                                                          \
+  if (W4_DO_READS) XN[1] = w4_frag(XA, 1 * 32 + frow, (KS) * 2 + fhalf);                         \
+  DMA1;                                                                                          \
+  if (W4_DO_READS) {                                                                             \
+    WN[1] = w4_frag(WW, 1 * 32 + frow, (KS) * 2 + fhalf);                                        \
+    XN[2] = w4_frag(XA, 2 * 32 + frow, (KS) * 2 + fhalf);                                        \
+  }                                                                                              \
+  DMA2;                                                                                          \
+  if (W4_DO_READS) XN[3] = w4_frag(XA, 3 * 32 + frow, (KS) * 2 + fhalf);                         \
+  DMA3;                                                                                          \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[0], acc[0][0], 0, 0, 0);         \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[1], acc[1][0], 0, 0, 0);         \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[0], acc[0][1], 0, 0, 0);         \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[1], acc[1][1], 0, 0, 0);         \
+  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[2], acc[2][0], 0, 0, 0);         \
+  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[2], acc[2][1], 0, 0, 0);         \
+  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[3], acc[3][0], 0, 0, 0);         \
+  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[3], acc[3][1], 0, 0, 0);         \
+  _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_) {                                             \
+    __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                     \
+    if (n_ < 6) __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                         \
+    if (n_ == 1 || n_ == 2 || n_ == 4 || n_ == 5) __builtin_amdgcn_sched_group_barrier(W4_SGB_VMEM, 1, 0); \
+  }                                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+
 template <int EPI, int ACT>
+__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t mw, int nw, int lane, char* slab) {
+  const int lm = lane & 31, lh = lane >> 5;
+  const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
+  if constexpr (EPI == EPI_BF16) {
+    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7)
+    f32x4 b4[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        b4[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + nw + c8 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)w4_epi_act<ACT>(acc[i][j][g * 4 + r] + b4[j][g][r]);
+          *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
+        }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int64_t m = mw + i * 32 + row;
+#ifdef W4_NOSTORE
+        if (m < p.M && v[0] == (bf16_t)12345.f) *reinterpret_cast<bf16x8*>(outp + m * p.ldc) = v;
+#else
+        if (m < p.M) *reinterpret_cast<bf16x8*>(outp + m * p.ldc) = v;
+#endif
+      }
+    }
+  } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
+    f32x4 res[2][4];
+    auto fetch = [&](int s, f32x4 (&dst)[4]) {
+      const int i = s >> 1, j = s & 1;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int64_t m = min(mw + i * 32 + tt * 8 + rrow, p.M - 1);
+        dst[tt] = *reinterpret_cast<const f32x4*>(p.resid + m * p.ldc + nw + j * 32 + c8 * 4);
+      }
+    };
+    if (p.resid) fetch(0, res[0]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int i = s >> 1, j = s & 1;
+      if (p.resid && s + 1 < 8) fetch(s + 1, res[(s + 1) & 1]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
+        *reinterpret_cast<f32x4*>(slab + lm * 128 + (((g * 2 + lh) ^ (lm & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+        const int64_t m = mw + i * 32 + row;
+        if (p.resid) v += res[s & 1][tt];
+        if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * p.ldc + nw + j * 32 + c8 * 4) = v;
+      }
+    }
+  }
+}
+
+// (kernel bodies live in __device__ functions: the buffer-descriptor types they use are invisible to the host pass,
+// which otherwise drops the kernel's launch stub)
+template <int EPI, int ACT>
+__device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (int)((p.M + 255) / 256);
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  if (slot >= cnt) return;
+  const int nk = p.K / WBK;
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int x_off = wm * 128 * WROWB, w_off = wn * 64 * WROWB;
+
+  W4CurA<8> CA;
+  W4CurW CW;
+  CA.li = CW.li = slot;
+  CA.kt = CW.kt = 0;
+  w4_setup_a<8>(CA, p, base + slot, tiles_n, lda, wave, lane);
+  w4_setup_w(CW, p, base + slot, tiles_n, ldw, wave, lane);
+  auto advance_a = [&]() {
+    if (++CA.kt == nk) {
+      CA.kt = 0;
+      if (CA.li + slots < cnt) { CA.li += slots; w4_setup_a<8>(CA, p, base + CA.li, tiles_n, lda, wave, lane); }
+    }
+  };
+  auto advance_w = [&]() {
+    if (++CW.kt == nk) {
+      CW.kt = 0;
+      if (CW.li + slots < cnt) { CW.li += slots; w4_setup_w(CW, p, base + CW.li, tiles_n, ldw, wave, lane); }
+    }
+  };
+
+  int a_c = W_AOFF, a_1 = W_AOFF + W_SLOT, a_2 = W_AOFF + 2 * W_SLOT;
+  int w_c = W_WOFF, w_1 = W_WOFF + W_SLOT;
+
+  // prologue: A(0) W(0) | A(1) W(1)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_c, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_c, wave);
+  advance_w();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_1, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_1, wave);
+  advance_w();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 x0[4], w0[2], x1[4], w1[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x0[i] = w4_frag(smem + a_c + x_off, i * 32 + frow, fhalf);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w0[j] = w4_frag(smem + w_c + w_off, j * 32 + frow, fhalf);
+
+  // Vector-memory operations retire in issue order.  Everything the FIRST barrier after an epilogue waits for
+  // (A(g+1), W(g+1)) was issued before that epilogue's stores, so that barrier may leave the stores in flight
+  // (vmcnt(4 + NST)); only the second one, a whole K-tile later, needs them retired.
+  constexpr int NST = (EPI == EPI_BF16) ? 16 : 32;      // global stores per wave and epilogue (full tile)
+  bool stores_pending = false;
+  int c_li = slot;
+  while (true) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* xa = smem + a_c + x_off;
+      const char* ww = smem + w_c + w_off;
+      // ks0: compute (g,0), read (g,1)
+      W8_STEP(x1, w1, xa, ww, 1, x0, w0, (void)0, (void)0, (void)0, (void)0)
+      // ks1: compute (g,1), read (g,2); A(g+2) pieces 0..1
+      W8_STEP(x0, w0, xa, ww, 2, x1, w1, w4_piece_a<8>(CA, 0, smem + a_2, wave), (void)0, w4_piece_a<8>(CA, 1, smem + a_2, wave), (void)0)
+      // ks2: compute (g,2), read (g,3); A(g+2) pieces 2..3
+      W8_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a<8>(CA, 2, smem + a_2, wave), (void)0, w4_piece_a<8>(CA, 3, smem + a_2, wave), (void)0)
+      advance_a();
+      // A(g+1) and W(g+1) have landed (only A(g+2), and right after an epilogue its stores, may still be in flight);
+      // every wave is done reading A(g), W(g)
+      if (stores_pending) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
+        stores_pending = false;
+      } else {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ks3: compute (g,3), read (g+1,0) (possibly of the next output tile); W(g+2) -> slot of W(g)
+      W8_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w<8>(CW, 0, ldw, smem + w_c, wave),
+              w4_piece_w<8>(CW, 1, ldw, smem + w_c, wave), w4_piece_w<8>(CW, 2, ldw, smem + w_c, wave),
+              w4_piece_w<8>(CW, 3, ldw, smem + w_c, wave))
+      advance_w();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+    }
+    const int t = base + c_li;
+    const int64_t m_cur = (int64_t)(t / tiles_n) * 256;
+    const int n_cur = (t % tiles_n) * 256;
+#ifdef W4_NOEPI
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+    w8_epilogue<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 64, lane, smem + a_2 + wave * 4096);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+#ifndef W4_STRICT_WAIT
+    // a full tile issued exactly NST stores per wave.  Only the fp32 + residual epilogue uses the relaxed wait:
+    // measured -4..-5 % on the out-proj / fc2 shapes, but +29 % on the bf16 QKV shape (N = 2304), where letting
+    // every CU run ahead with 16 more stores in flight makes the HBM write bursts collide
+    stores_pending = (EPI == EPI_F32) && (m_cur + 256 <= p.M);
+#endif
+#endif
+    c_li += slots;
+    if (c_li >= cnt) break;
+  }
+}
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  w4_body<EPI, ACT>(p, smem);
+}
+
+template <int EPI, int ACT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_w8_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  w8_body<EPI, ACT>(p, smem);
+}
+
+template <int EPI, int ACT, int NWV>
 int launch_w4(const GemmArgs& p, hipStream_t st) {
-  auto kern = gemm_bf16_w4_kernel<EPI, ACT>;
+  void (*kern)(GemmArgs) = nullptr;
+  if constexpr (NWV == 8) kern = gemm_bf16_w8_kernel<EPI, ACT>;
+  else kern = gemm_bf16_w4_kernel<EPI, ACT>;
   static bool attr_done = false;
   if (!attr_done) {
     CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM));
@@ -363,7 +622,7 @@ int launch_w4(const GemmArgs& p, hipStream_t st) {
   }
   const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
   const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W_SMEM, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), W_SMEM, st, p);
   return check_hip(hipGetLastError(), "gemm_bf16_w4 launch");
 }
 
@@ -374,17 +633,22 @@ bool gemm_bf16_w4_ok(const GemmArgs& p, int epi) {
          (int64_t)256 * (p.lda ? p.lda : p.K) * 2 < 0x7fffffff && (int64_t)256 * (p.ldw ? p.ldw : p.K) * 2 < 0x7fffffff;
 }
 
-int gemm_bf16_w4(const GemmArgs& p, int epi, int act, hipStream_t st) {
+template <int NWV>
+static int gemm_bf16_w_t(const GemmArgs& p, int epi, int act, hipStream_t st) {
   CACO_REQUIRE(gemm_bf16_w4_ok(p, epi), "gemm_bf16_w4: shape not supported");
   if (epi == EPI_BF16) {
-    if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE>(p, st);
-    if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU>(p, st);
-    if (act == ACT_GELU) return launch_w4<EPI_BF16, ACT_GELU>(p, st);
+    if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, NWV>(p, st);
+    if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, NWV>(p, st);
+    if (act == ACT_GELU) return launch_w4<EPI_BF16, ACT_GELU, NWV>(p, st);
   } else if (epi == EPI_F32 && act == ACT_NONE) {
-    return launch_w4<EPI_F32, ACT_NONE>(p, st);
+    return launch_w4<EPI_F32, ACT_NONE, NWV>(p, st);
   }
   set_error("gemm_bf16_w4: unsupported epilogue %d / activation %d", epi, act);
   return CACO_ERR_INVALID;
+}
+
+int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st) {
+  return waves == 8 ? gemm_bf16_w_t<8>(p, epi, act, st) : gemm_bf16_w_t<4>(p, epi, act, st);
 }
 
 }  // namespace caco

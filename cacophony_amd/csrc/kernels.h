@@ -25,7 +25,7 @@ int set_gemm_tile_config(int tile);
 int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w4_ok(const GemmArgs& p, int epi);                         // gemm_w4.hip
-int gemm_bf16_w4(const GemmArgs& p, int epi, int act, hipStream_t st);
+int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st);   // waves: 4 or 8
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
              hipStream_t st);
 

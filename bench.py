@@ -203,7 +203,7 @@ def main():
             stages[name] = ent
         dom = stages.get("audio.gemm_fc1")
         if dom:
-            roofline = {"kernel": "gemm_bf16_kernel<EPI_BF16, SiLU> (audio MLP fc1: [128000,768] x [3072,768]^T)",
+            roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [128000,768] x [3072,768]^T)",
                         "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["frac"], "traffic": None,
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"]}

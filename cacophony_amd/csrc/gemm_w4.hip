@@ -67,6 +67,19 @@ __device__ __forceinline__ float w4_epi_act(float x) {
   return x;
 }
 
+// Tile order.  The n-tiles are processed in groups of G (p.ngroup): all M panels of one group, then the next group,
+// n fastest inside a group.  A group's weight rows (G x 256 x K bf16) then stay in the XCD's 4 MiB L2 for the whole
+// pass instead of being re-streamed through it once per M panel.  Off by default (launch_w4).
+__device__ __forceinline__ void w4_decode(int t, int tiles_n, int tiles_m, int G, int& tm, int& tn) {
+  const int per = tiles_m * G;
+  const int g = t / per;                 // groups before the last one are full
+  const int n0 = g * G;
+  const int gw = min(G, tiles_n - n0);   // width of this group
+  const int rem = t - g * per;
+  tm = rem / gw;
+  tn = n0 + rem % gw;
+}
+
 // Load cursors.  Each walks the K-tiles of this workgroup's output tiles in order, ahead of the compute cursor.
 template <int NWV>
 struct W4CurA {
@@ -85,7 +98,9 @@ __device__ __forceinline__ void w4_setup_a(W4CurA<NWV>& C, const GemmArgs& p, in
 #ifdef W4_SAMEADDR
   t = 0;
 #endif
-  const int64_t m0 = (int64_t)(t / tiles_n) * 256;
+  int tm, tn;
+  w4_decode(t, tiles_n, (int)((p.M + 255) / 256), p.ngroup, tm, tn);
+  const int64_t m0 = (int64_t)tm * 256;
   C.r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + m0 * lda), 0, 0x7fffffff, 0x00020000);
   const int r8 = wave * 8 + (lane >> 3);                         // row within a span of NWV * 8 rows
   const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7); // (row >> 1) & 7 is the same for every span
@@ -97,7 +112,9 @@ __device__ __forceinline__ void w4_setup_w(W4CurW& C, const GemmArgs& p, int t, 
 #ifdef W4_SAMEADDR
   t = 0;
 #endif
-  const int n0 = (t % tiles_n) * 256;
+  int tm, tn;
+  w4_decode(t, tiles_n, (int)((p.M + 255) / 256), p.ngroup, tm, tn);
+  const int n0 = tn * 256;
   C.r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * ldw), 0, 0x7fffffff, 0x00020000);
   const int r8 = wave * 8 + (lane >> 3);
   const int chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
@@ -330,8 +347,10 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
       { const int t_ = w_c; w_c = w_1; w_1 = t_; }
     }
     const int t = base + c_li;
-    const int64_t m_cur = (int64_t)(t / tiles_n) * 256;
-    const int n_cur = (t % tiles_n) * 256;
+    int tm_, tn_;
+    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
+    const int64_t m_cur = (int64_t)tm_ * 256;
+    const int n_cur = tn_ * 256;
 #ifdef W4_NOEPI
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -567,8 +586,10 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
       { const int t_ = w_c; w_c = w_1; w_1 = t_; }
     }
     const int t = base + c_li;
-    const int64_t m_cur = (int64_t)(t / tiles_n) * 256;
-    const int n_cur = (t % tiles_n) * 256;
+    int tm_, tn_;
+    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
+    const int64_t m_cur = (int64_t)tm_ * 256;
+    const int n_cur = tn_ * 256;
 #ifdef W4_NOEPI
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -622,7 +643,14 @@ int launch_w4(const GemmArgs& p, hipStream_t st) {
   }
   const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
   const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), W_SMEM, st, p);
+  GemmArgs q = p;
+  {   // n-tiles per L2 group.  Default: one group (n fastest over all of N).  Grouping was measured on the encoder
+      // shapes (CACO_W_NGROUP = 2..6): within +-2 % - the weight re-reads it removes are served by the Infinity Cache.
+    static const int env_g = getenv("CACO_W_NGROUP") ? atoi(getenv("CACO_W_NGROUP")) : 0;
+    const int tiles_n = p.N / 256;
+    q.ngroup = (env_g > 0 && env_g < tiles_n) ? env_g : tiles_n;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), W_SMEM, st, q);
   return check_hip(hipGetLastError(), "gemm_bf16_w4 launch");
 }
 

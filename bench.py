@@ -202,10 +202,18 @@ def main():
                 ent.update(bound="hbm", achieved_gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
             stages[name] = ent
         dom = stages.get("audio.gemm_fc1")
+        traffic = None      # HBM bytes per launch of the same kernel from the TCC PMC counters (tools/pmc_hbm.sh, calibrated
+        try:                # on a 1 GiB stream; rocprofv3 cannot run inside this process), newest committed measurement
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")))
+            if cands:
+                traffic = int(json.load(open(cands[-1]))["hbm_bytes"])
+        except Exception:
+            traffic = None
         if dom:
             roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [128000,768] x [3072,768]^T)",
                         "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": dom["frac"], "traffic": None,
+                        "frac": dom["frac"], "traffic": traffic,
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"]}
 
     cpu = None

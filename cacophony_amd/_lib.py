@@ -54,6 +54,7 @@ _SIGNATURES = {
     "caco_encode_audio": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "caco_similarity": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "caco_l2_normalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "caco_topk": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "caco_mae_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "caco_workspace_bytes": (_i64, [_vp]),
     "caco_set_gemm_tile": (_i32, [_i32]),

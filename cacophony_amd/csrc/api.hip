@@ -654,6 +654,13 @@ int caco_similarity(const float* a, int32_t na, const float* t, int32_t nt, int3
   return CACO_OK;
 }
 
+int caco_topk(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride, int32_t k, int32_t* idx,
+              float* val, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CACO_STAGE("retrieval.topk", topk_rows(sim, rows, cols, row_stride, col_stride, k, idx, val, st));
+  return CACO_OK;
+}
+
 int caco_l2_normalize(const float* x, int32_t rows, int32_t dim, float* out, void* stream) {
   return l2_normalize(x, rows, dim, out, (hipStream_t)stream);
 }

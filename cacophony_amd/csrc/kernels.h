@@ -53,6 +53,10 @@ int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_
 int attn_pool(const bf16_t* kv, const float* query, const float* mask, int batch, int seq, int hidden, int heads,
               float scale, float* out, hipStream_t st);
 
+// topk.hip: per-row top-k (value desc, index asc) through arbitrary strides
+int topk_rows(const float* sim, int rows, int cols, int64_t row_stride, int64_t col_stride, int k, int* idx, float* val,
+              hipStream_t st);
+
 // mel.hip
 int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias,
                  void* out, int mode, float* tinds, float* finds, float* mask, hipStream_t st);

@@ -255,3 +255,27 @@ def make_mae_split(batch: int, n_patches: int = 496, n_visible: int = 100, num_f
         "restore_time_inds": (res // num_freq_patches).astype(np.float32),
         "restore_freq_inds": (res % num_freq_patches).astype(np.float32),
     }
+
+
+def make_retrieval_scenario(seed: int = 7, n_audio: int = 40, caps_per: int = 3, dim: int = 32, signal: float = 0.3):
+    """Seeded synthetic retrieval set in the reference's bookkeeping (src/eval/eval_caco_torch.py:355-395): clip names,
+    caption strings (one string occurs under two clips, one string twice under the same clip), the two ground-truth
+    dicts, and L2-normalised audio / text embeddings whose similarity is informative but far from perfect."""
+    rng = np.random.RandomState(seed)
+    all_audio = [f"clip_{i:03d}.wav" for i in range(n_audio)]
+    all_text, gt_audio_text, gt_text_audio = [], {a: [] for a in all_audio}, {}
+    for i, a in enumerate(all_audio):
+        for c in range(caps_per):
+            s = f"caption {i}-{c}"
+            if i in (5, 17) and c == 0:
+                s = "a dog barks"                 # same string under two clips: the later clip owns it in gt_text_audio
+            if i == 9 and c == 2:
+                s = "caption 9-1"                 # duplicate string inside one clip's list
+            gt_audio_text[a].append(s)
+            gt_text_audio[s] = a
+            all_text.append(s)
+    A = rng.randn(n_audio, dim).astype(np.float32)
+    T = np.repeat(A, caps_per, 0) * signal + rng.randn(n_audio * caps_per, dim).astype(np.float32)
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    T /= np.linalg.norm(T, axis=1, keepdims=True)
+    return all_audio, all_text, gt_audio_text, gt_text_audio, A, T

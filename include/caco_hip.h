@@ -111,6 +111,13 @@ int caco_encode_audio(caco_model* m, const float* wav_dev, int32_t batch, int64_
  * a_dev [na, dim], t_dev [nt, dim], out_dev [na, nt] with row stride ld_out (>= nt). */
 int caco_similarity(const float* a_dev, int32_t na, const float* t_dev, int32_t nt, int32_t dim, float scale,
                     float* out_dev, int32_t ld_out, void* stream);
+/* Retrieval scoring, device part: the first k columns of argsort(-sim, dim=-1) per row
+ * (src/eval/eval_caco_torch.py:402-408; src/eval/eval_utils.py:18-54 reads only the first 10).  sim_dev is read
+ * as sim[r * row_stride + c * col_stride] (elements), so audio->text (rows = clips) and text->audio (rows = captions)
+ * both run on one stored matrix.  idx_dev int32 [rows, k] (value descending, ties by ascending index, -1 padding when
+ * cols < k); val_dev fp32 [rows, k] or NULL.  1 <= k <= 64. */
+int caco_topk(const float* sim_dev, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride, int32_t k,
+              int32_t* idx_dev, float* val_dev, void* stream);
 /* x / ||x + 1e-10||_2 per row (src/caco_torch/caco.py:144-146), in place allowed. */
 int caco_l2_normalize(const float* x_dev, int32_t rows, int32_t dim, float* out_dev, void* stream);
 

@@ -562,3 +562,52 @@ class AudioMAEOracle:
             h = audio_encoder_layer(o, h, keep, P, f"decoder.layers.{n}", dc.num_heads, dc.layer_norm_eps)
         h = layer_norm(o, h, P["decoder.norm.weight"], P["decoder.norm.bias"], dc.layer_norm_eps)
         return o.to_numpy(linear(o, h, P["decoder.output_proj.weight"], P["decoder.output_proj.bias"]))
+
+
+# ----------------------------------------------------------------------------------------------
+# retrieval scoring
+# ----------------------------------------------------------------------------------------------
+def argsort_desc(scores: np.ndarray, k: int = 10) -> np.ndarray:
+    """First k columns of argsort(-scores, axis=-1): src/eval/eval_caco_torch.py:403,407 (`torch.argsort(-logits)`;
+    only the first 10 columns are consumed, eval_utils.py:26).  Stable sort: ties keep ascending index order."""
+    order = np.argsort(-np.asarray(scores, dtype=np.float64), axis=-1, kind="stable")
+    return order[..., :k].astype(np.int32)
+
+
+def jackknife_mean(data, confidence_level: float = 0.95):
+    """astropy.stats.jackknife_stats(data, np.mean, 0.95) as called at src/eval/eval_utils.py:57-67 (astropy absent
+    here; published algorithm: leave-one-out statistics, bias (n-1)(mean_jack - stat), normal-quantile interval)."""
+    from scipy.special import erfinv
+    x = np.asarray(data, dtype=np.float64)
+    n = x.size
+    stat = x.mean()
+    jack = np.array([np.delete(x, i).mean() for i in range(n)])
+    mean_jack = jack.mean()
+    bias = (n - 1) * (mean_jack - stat)
+    std_err = np.sqrt((n - 1) * np.mean((jack - mean_jack) ** 2))
+    est = stat - bias
+    z = np.sqrt(2.0) * erfinv(confidence_level)
+    return float(est), float(bias), float(std_err), (float(est - z * std_err), float(est + z * std_err))
+
+
+def retrieval_hits(indices, all_querys, all_keys, gt_query_key, retrieval_type="at"):
+    """Per-query R1 / R5 / R10 / mAP10 lists of compute_retrieval_metric, src/eval/eval_utils.py:18-54."""
+    R1, R5, R10, mAP10 = [], [], [], []
+    for i, query in enumerate(all_querys):
+        pred_keys = [all_keys[int(j)] for j in indices[i, :10]]            # :26
+        if retrieval_type == "at":                                         # :28-39
+            preds, taken = [], []
+            for pred in pred_keys:
+                ok = (pred not in taken) and (pred in gt_query_key[query])
+                if ok:
+                    taken.append(pred)
+                preds.append(ok)
+            preds = np.asarray(preds)
+        else:                                                              # :41-42
+            preds = np.asarray([gt_query_key[query] == pred for pred in pred_keys])
+        R1.append(float(np.any(preds[:1])))                                # :45-47
+        R5.append(float(np.any(preds[:5])))
+        R10.append(float(np.any(preds[:10])))
+        positions = np.arange(1, 11, dtype=float)[preds[:10] > 0]          # :49-54
+        mAP10.append(float(np.mean(np.arange(1, len(positions) + 1, dtype=float) / positions)) if len(positions) else 0.0)
+    return {"R1": R1, "R5": R5, "R10": R10, "mAP10": mAP10}

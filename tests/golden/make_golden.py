@@ -231,6 +231,38 @@ def golden_mae(refs, tag, layers):
     print(f"mae_{tag}.npz", y.shape, float(np.abs(y).mean()))
 
 
+def golden_retrieval():
+    """compute_retrieval_metric of the reference (src/eval/eval_utils.py:18-67) on the seeded scenario.  astropy is not
+    installed: its jackknife_stats is replaced by a recorder, so the per-query R1/R5/R10/mAP10 lists ARE the
+    reference's; the interval arithmetic is pinned separately against the closed form in the tests."""
+    import contextlib
+    import io
+    from src.eval import eval_utils as ref_utils
+    recorded = []
+
+    class _Jack:
+        @staticmethod
+        def jackknife_stats(data, fn, conf):
+            recorded.append(np.asarray(data, dtype=np.float64).copy())
+            m = float(fn(data))
+            return m, 0.0, 0.0, (m, m)
+
+    ref_utils.jackknife = _Jack
+    all_audio, all_text, gt_at, gt_ta, A, T = synth.make_retrieval_scenario()
+    logits_ar = torch.from_numpy(T) @ torch.from_numpy(A).T                       # eval_caco_torch.py:398
+    at_indices = torch.argsort(-logits_ar.T, dim=-1, stable=True).cpu().numpy()   # :403 (stable: ties by index)
+    ta_indices = torch.argsort(-logits_ar, dim=-1, stable=True).cpu().numpy()     # :407
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref_utils.compute_retrieval_metric(at_indices, all_audio, all_text, gt_at)
+        ref_utils.compute_retrieval_metric(ta_indices, all_text, all_audio, gt_ta, "ta")
+    names = ["R1", "R5", "R10", "mAP10"]
+    out = {f"at_{n}": recorded[i] for i, n in enumerate(names)}
+    out.update({f"ta_{n}": recorded[4 + i] for i, n in enumerate(names)})
+    np.savez_compressed(os.path.join(OUT, "retrieval.npz"), logits_ar=logits_ar.numpy(), at_top10=at_indices[:, :10].astype(np.int32),
+                        ta_top10=ta_indices[:, :10].astype(np.int32), **out)
+    print("retrieval.npz", {k: float(v.mean()) for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -243,6 +275,7 @@ def main():
     golden_varlen(refs)
     golden_mae(refs, "tiny", 2)
     golden_mae(refs, "full", 12)
+    golden_retrieval()
 
 
 if __name__ == "__main__":

@@ -41,7 +41,6 @@ struct MelTables {            // device image, loaded verbatim into LDS
 static_assert(sizeof(MelTables) % 16 == 0, "MelTables must be float4-copyable");
 
 constexpr int XP = 272;       // complex pitch per frame: 16*17, and 2*XP = 32 (mod 64) banks
-constexpr int MP = 260;       // magnitude pitch per frame (floats)
 
 struct __attribute__((aligned(16))) MelSmem {
   float samp[SPAN_PAD];             // samples, later the [16][128] log-mel tile
@@ -97,136 +96,147 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 template <int MODE>
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int64_t n_samples,
                                                   const MelTables* __restrict__ tables, void* __restrict__ out,
-                                                  int frames_out, int rows_out, int S, float scale, float bias) {
+                                                  int frames_out, int rows_out, int S, float scale, float bias, int nblk) {
   __shared__ MelSmem sm;
   const int tid = threadIdx.x, fl = tid >> 4, t = tid & 15;
-  const int blk = blockIdx.x, b = blockIdx.y;
-  const int f0 = blk * FPB;
+  const int b = blockIdx.y;
   const float* w = wav + (int64_t)b * n_samples;
-  const int64_t g0 = (int64_t)f0 * HOP + WOFF;
 
-  // ---- stage constant tables and the sample span -------------------------------------------------
+  // ---- constant tables: staged ONCE per workgroup; the workgroup then walks several 16-frame blocks ----------
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(tables);
     f32x4* dst = reinterpret_cast<f32x4*>(&sm.tab);
     for (int i = tid; i < (int)(sizeof(MelTables) / 16); i += 256) dst[i] = src[i];
   }
-  if ((n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(wav) & 15) == 0) {
-    for (int i = tid; i < SPAN / 4; i += 256) {
-      const int64_t g = g0 + 4 * i;
-      f32x4 v;
-      if (g + 3 < n_samples) {
-        v = *reinterpret_cast<const f32x4*>(w + g);
-      } else {
+  const bool vec_ok = (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(wav) & 15) == 0;
+
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int f0 = blk * FPB;
+    const int64_t g0 = (int64_t)f0 * HOP + WOFF;
+    __syncthreads();          // previous block's tile (aliases samp) fully stored; tables visible on the first pass
+    if (vec_ok) {
+      for (int i = tid; i < SPAN / 4; i += 256) {
+        const int64_t g = g0 + 4 * i;
+        f32x4 v;
+        if (g + 3 < n_samples) {
+          v = *reinterpret_cast<const f32x4*>(w + g);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (g + r < n_samples) ? w[g + r] : 0.f;   // zero pad, :78
+          for (int r = 0; r < 4; ++r) v[r] = (g + r < n_samples) ? w[g + r] : 0.f;   // zero pad, :78
+        }
+        *reinterpret_cast<f32x4*>(&sm.samp[4 * i]) = v;
       }
-      *reinterpret_cast<f32x4*>(&sm.samp[4 * i]) = v;
+    } else {
+      for (int i = tid; i < SPAN; i += 256) sm.samp[i] = (g0 + i < n_samples) ? w[g0 + i] : 0.f;
     }
-  } else {
-    for (int i = tid; i < SPAN; i += 256) sm.samp[i] = (g0 + i < n_samples) ? w[g0 + i] : 0.f;
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
-  float2 v[16];
+    // From here to the tile write every exchange stays inside one frame = 16 lanes of ONE wave: LDS operations of a
+    // wave execute in order, so wave-level ordering (no workgroup barrier) is enough between the passes.
+    // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
+    float2 v[16];
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) {
-    const int n = t + 16 * n2;                 // complex index; real samples 2n, 2n+1 of the 512 frame
-    float2 z = make_float2(0.f, 0.f);
-    if (n >= WOFF / 2 && n < (WOFF + WIN) / 2) {
-      const int wi = 2 * n - WOFF;             // window tap of the even sample
-      const float2 x = *reinterpret_cast<const float2*>(&sm.samp[fl * HOP + wi]);
-      const float2 h = *reinterpret_cast<const float2*>(&sm.tab.hann[wi]);
-      z = make_float2(x.x * h.x, x.y * h.y);
+    for (int n2 = 0; n2 < 16; ++n2) {
+      const int n = t + 16 * n2;                 // complex index; real samples 2n, 2n+1 of the 512 frame
+      float2 z = make_float2(0.f, 0.f);
+      if (n >= WOFF / 2 && n < (WOFF + WIN) / 2) {
+        const int wi = 2 * n - WOFF;             // window tap of the even sample
+        const float2 x = *reinterpret_cast<const float2*>(&sm.samp[fl * HOP + wi]);
+        const float2 h = *reinterpret_cast<const float2*>(&sm.tab.hann[wi]);
+        z = make_float2(x.x * h.x, x.y * h.y);
+      }
+      v[n2] = z;
     }
-    v[n2] = z;
-  }
-  dft16(v);
-  {
-    const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw256) + t * 16;
-    float2* col = sm.buf + fl * XP + t * 17;
+    dft16(v);
+    {
+      const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw256) + t * 16;
+      float2* col = sm.buf + fl * XP + t * 17;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2]);
-  }
-  __syncthreads();
-  // ---- pass B: thread k2 = t transforms over n1 -> X[k2 + 16 k1] -----------------------------------
+      for (int k2 = 0; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass B: thread k2 = t transforms over n1 -> X[k2 + 16 k1] -----------------------------------
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) v[n1] = sm.buf[fl * XP + n1 * 17 + t];
-  dft16(v);
-  __syncthreads();
+    for (int n1 = 0; n1 < 16; ++n1) v[n1] = sm.buf[fl * XP + n1 * 17 + t];
+    dft16(v);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) sm.buf[fl * XP + t + 16 * k1] = v[k1];
-  __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1) sm.buf[fl * XP + t + 16 * k1] = v[k1];
+    __builtin_amdgcn_wave_barrier();
 
-  // ---- real-input split + magnitude: R[k] = ((Zk + conj Z-k) - i w^k (Zk - conj Z-k)) / 2 ----------
-  float mag[17];
-  {
-    const float2* X = sm.buf + fl * XP;
-    const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw512);
+    // ---- real-input split + magnitude: R[k] = ((Zk + conj Z-k) - i w^k (Zk - conj Z-k)) / 2 ----------
+    float mag[17];
+    {
+      const float2* X = sm.buf + fl * XP;
+      const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw512);
+#pragma unroll
+      for (int j = 0; j < 17; ++j) {
+        const int k = t + 16 * j;
+        float m = 0.f;
+        if (k <= 256) {
+          const float2 zk = X[k & 255];
+          const float2 zr = X[(256 - k) & 255];
+          const float2 zc = make_float2(zr.x, -zr.y);
+          const float2 e = cadd(zk, zc), d = csub(zk, zc);
+          const float2 wd = cmul(tw[k], d);
+          const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
+          m = sqrtf(re * re + im * im);
+        }
+        mag[j] = m;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* magbuf = reinterpret_cast<float*>(sm.buf) + fl * (2 * XP);     // inside this frame's own spectrum region
 #pragma unroll
     for (int j = 0; j < 17; ++j) {
       const int k = t + 16 * j;
-      float m = 0.f;
-      if (k <= 256) {
-        const float2 zk = X[k & 255];
-        const float2 zr = X[(256 - k) & 255];
-        const float2 zc = make_float2(zr.x, -zr.y);
-        const float2 e = cadd(zk, zc), d = csub(zk, zc);
-        const float2 wd = cmul(tw[k], d);
-        const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
-        m = sqrtf(re * re + im * im);
-      }
-      mag[j] = m;
+      if (k <= 256) magbuf[k] = mag[j];
     }
-  }
-  __syncthreads();
-  float* magbuf = reinterpret_cast<float*>(sm.buf) + fl * MP;
-#pragma unroll
-  for (int j = 0; j < 17; ++j) {
-    const int k = t + 16 * j;
-    if (k <= 256) magbuf[k] = mag[j];
-  }
-  __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
-  // ---- mel filterbank (CSR gather) + log; thread owns mels t, t+16, ... ------------------------------
-  float* tile = sm.samp;                      // [16 frames][128 mels]; the samples are dead
+    // ---- mel filterbank (CSR gather) + log; thread owns mels t, t+16, ... ------------------------------
+    float melv[NMEL / 16];
 #pragma unroll
-  for (int j = 0; j < NMEL / 16; ++j) {
-    const int m = t + 16 * j;
-    const int st = sm.tab.mel_start[m], off = sm.tab.mel_off[m], cnt = sm.tab.mel_cnt[m];
-    float acc = 0.f;
-    for (int i = 0; i < cnt; ++i) acc += magbuf[st + i] * sm.tab.melw[off + i];
-    tile[fl * NMEL + m] = logf(acc + 1e-5f) * scale + bias;
-  }
-  __syncthreads();
-
-  // ---- coalesced 16/32-byte stores -----------------------------------------------------------------
-  if constexpr (MODE == MEL_NATURAL_F32) {
-    const int frame = f0 + (tid >> 4);
-    if (frame < frames_out) {
-      const int m0 = (tid & 15) * 8;
-      float* op = reinterpret_cast<float*>(out) + ((int64_t)b * frames_out + frame) * NMEL + m0;
-      const float* tp = tile + (tid >> 4) * NMEL + m0;
-      *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
-      *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
+    for (int j = 0; j < NMEL / 16; ++j) {
+      const int m = t + 16 * j;
+      const int st = sm.tab.mel_start[m], off = sm.tab.mel_off[m], cnt = sm.tab.mel_cnt[m];
+      float acc = 0.f;
+      for (int i = 0; i < cnt; ++i) acc += magbuf[st + i] * sm.tab.melw[off + i];
+      melv[j] = __logf(acc + 1e-5f) * scale + bias;
     }
-  } else {
-    // patch row p = blk*8 + f holds mel[f0 + tt][f*16 + m], tt-major (eval_caco_torch.py:124-129)
-    const int f = tid >> 5, rem = tid & 31, tt = rem >> 1, m0 = (rem & 1) * 8;
-    const int p = blk * 8 + f;
-    if (p < rows_out) {
-      const float* tp = tile + tt * NMEL + f * 16 + m0;
-      const int64_t o = ((int64_t)b * S + p) * 256 + tt * 16 + m0;
-      if constexpr (MODE == MEL_PATCH_BF16) {
-        bf16x8 pk;
+    __syncthreads();                            // every frame is done reading the samples: samp becomes the tile
+    float* tile = sm.samp;                      // [16 frames][128 mels]
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pk[r] = (bf16_t)tp[r];
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + o) = pk;
-      } else {
-        float* op = reinterpret_cast<float*>(out) + o;
+    for (int j = 0; j < NMEL / 16; ++j) tile[fl * NMEL + t + 16 * j] = melv[j];
+    __syncthreads();
+
+    // ---- coalesced 16/32-byte stores -----------------------------------------------------------------
+    if constexpr (MODE == MEL_NATURAL_F32) {
+      const int frame = f0 + (tid >> 4);
+      if (frame < frames_out) {
+        const int m0 = (tid & 15) * 8;
+        float* op = reinterpret_cast<float*>(out) + ((int64_t)b * frames_out + frame) * NMEL + m0;
+        const float* tp = tile + (tid >> 4) * NMEL + m0;
         *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
         *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
+      }
+    } else {
+      // patch row p = blk*8 + f holds mel[f0 + tt][f*16 + m], tt-major (eval_caco_torch.py:124-129)
+      const int f = tid >> 5, rem = tid & 31, tt = rem >> 1, m0 = (rem & 1) * 8;
+      const int p = blk * 8 + f;
+      if (p < rows_out) {
+        const float* tp = tile + tt * NMEL + f * 16 + m0;
+        const int64_t o = ((int64_t)b * S + p) * 256 + tt * 16 + m0;
+        if constexpr (MODE == MEL_PATCH_BF16) {
+          bf16x8 pk;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) pk[r] = (bf16_t)tp[r];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + o) = pk;
+        } else {
+          float* op = reinterpret_cast<float*>(out) + o;
+          *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
+          *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
+        }
       }
     }
   }
@@ -307,6 +317,13 @@ int ensure_tables() {
   return CACO_OK;
 }
 
+// workgroups per clip: enough to fill the chip a few times over, few enough that each one amortises its table
+// staging over several 16-frame blocks
+int mel_grid_x(int nblk, int batch) {
+  const int want = (2048 + batch - 1) / batch;      // ~8 workgroups per CU chip-wide
+  return nblk < want ? nblk : (want < 1 ? 1 : want);
+}
+
 }  // namespace
 
 int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias, void* out,
@@ -317,9 +334,10 @@ int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches
   if (rc) return rc;
   const int frames = (int)((n_samples + HOP - 1) / HOP);
   if (mode == MEL_NATURAL_F32) {
-    const dim3 grid((frames + FPB - 1) / FPB, batch);
+    const int nblk = (frames + FPB - 1) / FPB;
+    const dim3 grid(mel_grid_x(nblk, batch), batch);
     hipLaunchKernelGGL(mel_kernel<MEL_NATURAL_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, 0, 0,
-                       scale, bias);
+                       scale, bias, nblk);
     return check_hip(hipGetLastError(), "mel launch");
   }
   CACO_REQUIRE(max_patches > 0, "mel: max_patches must be positive");
@@ -328,13 +346,13 @@ int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches
   const int valid = full < max_patches ? full : max_patches;   // truncation branch keeps the first max_patches
   const int blocks = (valid + nfreq - 1) / nfreq;
   if (blocks > 0) {
-    const dim3 grid(blocks, batch);
+    const dim3 grid(mel_grid_x(blocks, batch), batch);
     if (mode == MEL_PATCH_BF16)
       hipLaunchKernelGGL(mel_kernel<MEL_PATCH_BF16>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
-                         max_patches, scale, bias);
+                         max_patches, scale, bias, blocks);
     else
       hipLaunchKernelGGL(mel_kernel<MEL_PATCH_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
-                         max_patches, scale, bias);
+                         max_patches, scale, bias, blocks);
     rc = check_hip(hipGetLastError(), "mel patch launch");
     if (rc) return rc;
   }

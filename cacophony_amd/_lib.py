@@ -58,6 +58,7 @@ _SIGNATURES = {
     "caco_mae_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "caco_workspace_bytes": (_i64, [_vp]),
     "caco_set_gemm_tile": (_i32, [_i32]),
+    "caco_set_ln_fold": (_i32, [_i32]),
     "caco_profile_enable": (C.c_int, [_i32]),
     "caco_profile_report": (_i64, [C.c_char_p, _i64]),
     "caco_op_gemm_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),

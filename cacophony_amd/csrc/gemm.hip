@@ -353,6 +353,10 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   const int cfg = gemm_tile_config();
   const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
   const bool p8_ok = p.N % 256 == 0 && p.K >= 2 * BK;
+  if (p.fold_mr || p.xb_out || p.stats_part) {      // LayerNorm folding lives in the 8-wave kernel's epilogue only
+    CACO_REQUIRE(gemm_bf16_w4_ok(p, epi), "gemm_bf16: LayerNorm folding needs N %% 256 == 0 and K %% 64 == 0");
+    return gemm_bf16_w4(p, epi, act, 8, st);
+  }
   if (cfg == 1256 && p8_ok) return launch_p8<EPI, ACT>(p, st);
   if ((cfg == 4256 || cfg == 8256) && gemm_bf16_w4_ok(p, epi)) return gemm_bf16_w4(p, epi, act, cfg == 8256 ? 8 : 4, st);
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);

@@ -411,23 +411,35 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
   const int lm = lane & 31, lh = lane >> 5;
   const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
   if constexpr (EPI == EPI_BF16) {
-    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7)
-    f32x4 b4[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        b4[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7).
+    // Bias (and the LayerNorm-fold column sums) are re-read from L1 per 4-column group instead of being held in 32-64
+    // registers across the whole epilogue: the accumulators already fill half the register file.
     bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + nw + c8 * 8;
+    const bool fold = p.fold_mr != nullptr;          // LayerNorm folded into this GEMM (kernels.h)
+    const float* bias_l = p.bias ? p.bias + nw + lh * 4 : nullptr;
+    const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      float nmr = 0.f, rstd = 1.f;                   // out = rstd * acc + (-mean * rstd) * c1 + bias
+      if (fold) {
+        const int64_t m = min(mw + i * 32 + lm, p.M - 1);
+        const float2 mr = *reinterpret_cast<const float2*>(p.fold_mr + 2 * m);
+        rstd = mr.y;
+        nmr = -mr.x * mr.y;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          f32x4 bb = bias_l ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (fold) {
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(c1_l + j * 32 + g * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] = __builtin_fmaf(nmr, cc[r], bb[r]);
+          }
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)w4_epi_act<ACT>(acc[i][j][g * 4 + r] + b4[j][g][r]);
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)w4_epi_act<ACT>(__builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]));
           *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
         }
 #pragma unroll
@@ -444,6 +456,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
     }
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
     f32x4 res[2][4];
+    float st1[4][4], st2[4][4];
     auto fetch = [&](int s, f32x4 (&dst)[4]) {
       const int i = s >> 1, j = s & 1;
 #pragma unroll
@@ -471,8 +484,38 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
         const int64_t m = mw + i * 32 + row;
         if (p.resid) v += res[s & 1][tt];
-        if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * p.ldc + nw + j * 32 + c8 * 4) = v;
+        if (m < p.M) {
+          const int64_t o = m * p.ldc + nw + j * 32 + c8 * 4;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
+          if (p.xb_out) {
+            bf16x4 b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x4*>(p.xb_out + o) = b;
+          }
+        }
+        if (p.stats_part) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
+          const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
+        }
       }
+    }
+    if (p.stats_part) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
+      const int nslot = p.N >> 6, slot = nw >> 6;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float a1 = st1[i][tt], a2 = st2[i][tt];
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+          }
+          const int64_t m = mw + i * 32 + tt * 8 + rrow;
+          if (c8 == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_part + (m * nslot + slot) * 2) = make_float2(a1, a2);
+        }
     }
   }
 }
@@ -570,7 +613,10 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
       // A(g+1) and W(g+1) have landed (only A(g+2), and right after an epilogue its stores, may still be in flight);
       // every wave is done reading A(g), W(g)
       if (stores_pending) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
+        // the producer form (bf16 copy + row statistics) issues 80 stores: the counter saturates at 63, which still
+        // retires everything older than the stores
+        if (EPI == EPI_F32 && p.xb_out) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
         stores_pending = false;
       } else {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -599,11 +645,17 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
     w8_epilogue<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 64, lane, smem + a_2 + wave * 4096);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+    // the next tile's first fragments are re-read here (ks3 already fetched them once): this way they are not live
+    // across the epilogue, which needs the registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = w4_frag(smem + a_c + x_off, i * 32 + frow, fhalf);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w0[j] = w4_frag(smem + w_c + w_off, j * 32 + frow, fhalf);
 #ifndef W4_STRICT_WAIT
     // a full tile issued exactly NST stores per wave.  Only the fp32 + residual epilogue uses the relaxed wait:
     // measured -4..-5 % on the out-proj / fc2 shapes, but +29 % on the bf16 QKV shape (N = 2304), where letting
     // every CU run ahead with 16 more stores in flight makes the HBM write bursts collide
-    stores_pending = (EPI == EPI_F32) && (m_cur + 256 <= p.M);
+    stores_pending = (EPI == EPI_F32) && (m_cur + 256 <= p.M) && (!p.xb_out == !p.stats_part);
 #endif
 #endif
     c_li += slots;

@@ -18,6 +18,14 @@ struct GemmArgs {
   int N, K, ldc;
   int lda, ldw;         // row strides of A / W in elements; 0 = K (dense)
   int ngroup;           // gemm_x: n-tiles per L2 group (0 = all)
+  // LayerNorm folding (8-wave kernel of gemm_w4.hip only; all null = plain GEMM).
+  // consumer, EPI_BF16:  out = act( rstd[m] * (acc[m,n] - mean[m] * fold_c1[n]) + bias[n] )
+  //   with A = the RAW (un-normalised) rows in bf16, W = gamma-scaled weights, bias = W.beta + b  (see api.hip)
+  const float* fold_mr;   // [M] (mean, rstd) pairs
+  const float* fold_c1;   // [N] row sums of the gamma-scaled bf16 weights
+  // producer, EPI_F32: besides out (fp32) also a bf16 copy of the same rows and per-row partial statistics
+  bf16_t* xb_out;         // [M, ldc] bf16 copy of out, or null
+  float* stats_part;      // [M, N/64] (sum, sum of squares) pairs over each wave's 64 columns, or null
 };
 
 int gemm_tile_config();
@@ -39,6 +47,9 @@ int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word,
 // x[m, :] (+)= sincos(time[m]) + freq_table[freq[m], :] (+ base[:] when base != null, replacing x)
 int add_pos_embed(float* x, const float* base, const float* time_inds, const float* freq_inds, const float* freq_table,
                   int64_t rows, int dim, int num_freq, hipStream_t st);
+// LayerNorm folding helpers: per-row (mean, rstd) from the GEMM epilogue's partial sums / from fp32 rows (+ bf16 copy)
+int ln_stats_finalize(const float* part, int nslot, int64_t rows, int dim, float eps, float* mr, hipStream_t st);
+int row_stats_bf16(const float* x, int64_t rows, int dim, float eps, bf16_t* xb, float* mr, hipStream_t st);
 int mask_i64_to_f32(const int64_t* in, float* out, int64_t n, hipStream_t st);
 int cast_f32_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st);
 // dst[b, dst_off + s, :] = src[b, s, :]  (fp32 rows of `dim`; used to concatenate decoder tokens)

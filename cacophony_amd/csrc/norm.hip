@@ -66,6 +66,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
 }
 
+// LayerNorm folding helpers (kernels.h GemmArgs::fold_*): (mean, rstd) per row
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int nslot, int64_t rows,
+                                                                float inv_dim, float eps, float* __restrict__ mr) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const float2* p = reinterpret_cast<const float2*>(part) + row * nslot;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < nslot; ++i) {
+    const float2 v = p[i];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mean = s1 * inv_dim;
+  const float var = fmaxf(s2 * inv_dim - mean * mean, 0.f);
+  reinterpret_cast<float2*>(mr)[row] = make_float2(mean, rsqrtf(var + eps));
+}
+
+__global__ __launch_bounds__(256) void row_stats_bf16_kernel(const float* __restrict__ x, int64_t rows, int dim, float eps,
+                                                             bf16_t* __restrict__ xb, float* __restrict__ mr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = dim >> 2;
+  float s = 0.f;
+  f32x4 v[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nchunk) {
+      v[c] = *reinterpret_cast<const f32x4*>(x + row * dim + ch * 4);
+      s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[c][r];
+      *reinterpret_cast<bf16x4*>(xb + row * dim + ch * 4) = o;
+    }
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c * 64 + lane < nchunk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q += (v[c][r] - mean) * (v[c][r] - mean);
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+  if (lane == 0) reinterpret_cast<float2*>(mr)[row] = make_float2(mean, rstd);
+}
+
 __global__ __launch_bounds__(256) void text_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos_ids,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
@@ -176,6 +225,20 @@ int layernorm(const float* x, const float* gamma, const float* beta, int64_t row
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
                      out_f32, out_bf16);
   return check_hip(hipGetLastError(), "layernorm launch");
+}
+
+int ln_stats_finalize(const float* part, int nslot, int64_t rows, int dim, float eps, float* mr, hipStream_t st) {
+  CACO_REQUIRE(part && mr && rows > 0 && nslot > 0 && dim > 0, "ln_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, nslot, rows,
+                     1.0f / (float)dim, eps, mr);
+  return check_hip(hipGetLastError(), "ln_stats_finalize launch");
+}
+
+int row_stats_bf16(const float* x, int64_t rows, int dim, float eps, bf16_t* xb, float* mr, hipStream_t st) {
+  CACO_REQUIRE(dim % 4 == 0 && dim > 0 && dim <= 256 * MAXC, "row_stats_bf16: dim %d must be a multiple of 4, <= %d", dim, 256 * MAXC);
+  CACO_REQUIRE(rows > 0 && x && xb && mr, "row_stats_bf16: bad arguments");
+  hipLaunchKernelGGL(row_stats_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, rows, dim, eps, xb, mr);
+  return check_hip(hipGetLastError(), "row_stats_bf16 launch");
 }
 
 int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,

@@ -135,6 +135,11 @@ int64_t caco_workspace_bytes(const caco_model* m);
  * 2256 / 1256 = force the 256x128 kernel / the one-workgroup-per-CU 256x256 phased kernel (tests, A/B runs).
  * Returns the mode now in force; any other value only queries. */
 int32_t caco_set_gemm_tile(int32_t tile);
+/* Tuning knob: LayerNorm folding in the audio stack (the LayerNorm passes disappear into the neighbouring GEMM
+ * epilogues; api.hip run_audio_layers).  0 = separate LayerNorm passes (default: measured slightly faster at batch
+ * 256, see api.hip), 1 = always fold, -1 = fold when the batch fills the chip.  Env CACO_LN_FOLD sets the initial
+ * mode.  Returns the mode now in force; any other value only queries. */
+int32_t caco_set_ln_fold(int32_t mode);
 /* Per-stage timing.  While enabled, every forward records a hipEvent pair around each launch group on the
  * caller's stream.  caco_profile_report synchronises on them, writes a JSON object
  * {"audio.gemm_fc1": {"ms": total, "n": launches}, ...} into buf (truncated to buflen) and resets the

@@ -88,16 +88,46 @@ def _check_against_golden(model, g, batch, vocab):
     return a_n, t_n
 
 
-def test_tiny_config_matches_reference_golden(tiny_model):
+@pytest.fixture(params=[0, 1], ids=["ln_pass", "ln_folded"])
+def ln_fold(request):
+    """Both forms of the audio stack: separate LayerNorm passes (small batches) and LayerNorm folded into the GEMM
+    epilogues (what batch 256 runs; forced here at test sizes)."""
+    from cacophony_amd import _lib
+    lib = _lib.load()
+    assert lib.caco_set_ln_fold(request.param) == request.param
+    yield request.param
+    lib.caco_set_ln_fold(0)
+
+
+def test_tiny_config_matches_reference_golden(tiny_model, ln_fold):
     _check_against_golden(tiny_model, load_golden("caco_tiny.npz"), 2, 1024)
 
 
-def test_full_config_matches_reference_golden(full_model):
+def test_full_config_matches_reference_golden(full_model, ln_fold):
     g = load_golden("caco_full.npz")
     a_n, t_n = _check_against_golden(full_model, g, 4, 50265)
     # centred cosine: discriminative even where raw cosines are dominated by a common direction
     assert _centred_cos(a_n.cpu().numpy(), g["audio_emb_norm"]).min() > CENTRED_TOL
     assert _centred_cos(t_n.cpu().numpy(), g["text_emb_norm"]).min() > CENTRED_TOL
+
+
+def test_ln_folded_stack_equals_ln_pass_stack(full_model):
+    """The folded form is an algebraic rewrite: hidden states of the two forms agree far inside the parity budget,
+    also for ragged batch sizes (M not a multiple of the 256-row tile) and large-mean rows."""
+    from cacophony_amd import _lib
+    lib = _lib.load()
+    for batch in (3, 5):
+        _, ab = _audio_batch(batch, start=40)
+        patches = ab["audio_patches"].clone()
+        patches[0] += 3.0                      # a clip whose rows carry a large common offset (mean >> std)
+        outs = []
+        for mode in (0, 1):
+            lib.caco_set_ln_fold(mode)
+            emb, hid = full_model.get_audio_embedding(patches, ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"])
+            outs.append((emb.cpu().numpy(), hid.cpu().numpy()))
+        lib.caco_set_ln_fold(0)
+        assert rel_l2(outs[1][1][:, :496], outs[0][1][:, :496]) < 4e-3
+        assert cosine_rows(outs[1][0], outs[0][0]).min() > 0.9999
 
 
 def test_one_layer_prefix_vs_oracle(full_state):
@@ -160,10 +190,17 @@ def test_full_batch_properties(full_model):
     assert ea.shape == (B, 768) and torch.isfinite(ea).all() and torch.isfinite(et).all()
     np.testing.assert_allclose(ea.norm(dim=1).cpu().numpy(), 1.0, atol=1e-3)
     np.testing.assert_allclose(et.norm(dim=1).cpu().numpy(), 1.0, atol=1e-3)
-    # batch-split invariance: every clip / caption is embedded independently of its batch mates
+    # batch-split invariance: every clip / caption is embedded independently of its batch mates (exact within one
+    # form of the audio stack; across the LayerNorm-pass and LayerNorm-folded forms within the parity tolerance)
+    from cacophony_amd import _lib
+    lib = _lib.load()
     ea_half = full_model.encode_audio(w[100:116])
+    lib.caco_set_ln_fold(1)
+    ea_half_pass = full_model.encode_audio(w[100:116])
+    lib.caco_set_ln_fold(0)
     et_half = full_model.encode_text(ids[100:116], tmask[100:116])
     assert (ea[100:116] - ea_half).abs().max().item() < 1e-5
+    assert (ea[100:116] - ea_half_pass).abs().max().item() < 1e-3
     assert (et[100:116] - et_half).abs().max().item() < 1e-5
     # permutation equivariance
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
@@ -212,7 +249,7 @@ def test_api_error_behaviour(tiny_model):
 
 
 @pytest.mark.parametrize("tag,layers", [("tiny", 2), ("full", 12)])
-def test_audiomae_matches_reference_golden(tag, layers):
+def test_audiomae_matches_reference_golden(tag, layers, ln_fold):
     g = load_golden(f"mae_{tag}.npz")
     enc = replace(C.default_audio_config(), num_layers=layers)
     sd = synth.make_audiomae_state(enc, enc)

@@ -52,10 +52,9 @@ def _flops(batch):
     return {
         "audio.patch_embed": 2 * M * P * H, "audio.gemm_qkv": 2 * M * H * 3 * H,
         "audio.attention": batch * S_attn, "audio.gemm_out": 2 * M * H * H, "audio.gemm_fc1": 2 * M * H * I,
-        "audio.gemm_fc2": 2 * M * I * H, "audio.pool_kv_gemm": 2 * M * H * 2 * H,
+        "audio.gemm_fc2": 2 * M * I * H,
         "text.gemm_qkv": 2 * Mt * H * 3 * H, "text.attention": batch * T_attn,
         "text.gemm_out": 2 * Mt * H * H, "text.gemm_fc1": 2 * Mt * H * I, "text.gemm_fc2": 2 * Mt * I * H,
-        "text.pool_kv_gemm": 2 * Mt * H * 2 * H,
     }
 
 

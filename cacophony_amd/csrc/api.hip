@@ -109,15 +109,17 @@ struct caco_model {
   std::vector<void*> owned;          // every device allocation holding weights
   // audio tower + pooler (caco.py:100-107)
   AudioStack enc, dec;
-  float* pool_query = nullptr;
-  Lin pool_kv;
+  // pooler with both projections folded out of the token dimension (pool.hip): wq = s * Wk_h^T q_h per head [heads, H];
+  // value projection as fp32 [H, H] + bias, applied to the pooled rows
+  float* pool_wq = nullptr;
+  float *pool_v_w = nullptr, *pool_v_b = nullptr;
   float *pool_out_w = nullptr, *pool_out_b = nullptr;   // fp32 [proj, H]
   // text tower (caco.py:110-113)
   float *word = nullptr, *pos = nullptr, *type0 = nullptr;
   LNp emb_ln;
   std::vector<TextLayer> tlayers;
-  float* tpool_query = nullptr;
-  Lin tpool_kv;
+  float* tpool_wq = nullptr;                            // [1, H]
+  float *tpool_v_w = nullptr, *tpool_v_b = nullptr;
   float *text_proj_w = nullptr, *text_proj_b = nullptr;
   float logit_scale = 0.f;
   // workspace arenas, one per (tower, stream): forwards enqueued on DIFFERENT streams (audio next to text, or two
@@ -255,6 +257,25 @@ struct Builder {
     return o;
   }
 
+  // wq[h, k] = scale * sum_d q[h*hd + d] * Wk[h*hd + d, k]  (Wk = rows [k_row0, k_row0 + H) of `wkey`, [wrows, H])
+  float* pool_wq(const float* q, const std::string& wkey, int wrows, int k_row0, int H, int heads, float scale) {
+    const HostTensor* w = get(wkey, {wrows, H});
+    if (!w || !q) return nullptr;
+    const int hd = H / heads;
+    std::vector<float> out((size_t)heads * H);
+    for (int h = 0; h < heads; ++h)
+      for (int k = 0; k < H; ++k) {
+        double acc = 0.0;
+        for (int d = 0; d < hd; ++d) acc += (double)q[h * hd + d] * w->data[(size_t)(k_row0 + h * hd + d) * H + k];
+        out[(size_t)h * H + k] = (float)(acc * scale);
+      }
+    return upload_f32(out.data(), out.size());
+  }
+  float* rows_f32(const std::string& key, int total, int cols, int r0, int rows) {
+    const HostTensor* t = cols > 0 ? get(key, {total, cols}) : get(key, {total});
+    return t ? upload_f32(t->data.data() + (size_t)r0 * (cols > 0 ? cols : 1), (size_t)rows * (cols > 0 ? cols : 1)) : nullptr;
+  }
+
   void audio_layers(AudioStack& s, const std::string& prefix, int nlayers, int H, int I) {
     for (int n = 0; n < nlayers; ++n) {
       const std::string p = prefix + ".layers." + std::to_string(n);
@@ -287,8 +308,13 @@ int build_weights(caco_model* m) {
     B.audio_layers(m->enc, ap, c.audio_layers, H, c.audio_intermediate);
     m->enc.norm = B.ln(ap + ".norm", H);
     if (!mae_names) {
-      m->pool_query = B.vec("audio_attention_pool.query", H);
-      m->pool_kv = B.lin("audio_attention_pool.kv_proj", 2 * H, H);
+      // kv_proj rows [0, H) = keys, [H, 2H) = values (caco.py:50-51 chunk(2)); query scaled by 1/sqrt(head_dim) (:55-63)
+      const HostTensor* pq = B.get("audio_attention_pool.query", {H});
+      const int phd = H / c.pool_heads;
+      m->pool_wq = B.pool_wq(pq ? pq->data.data() : nullptr, "audio_attention_pool.kv_proj.weight", 2 * H, 0, H, c.pool_heads,
+                             1.0f / sqrtf((float)phd));
+      m->pool_v_w = B.rows_f32("audio_attention_pool.kv_proj.weight", 2 * H, H, H, H);
+      m->pool_v_b = B.rows_f32("audio_attention_pool.kv_proj.bias", 2 * H, 0, H, H);
       m->pool_out_w = B.mat_f32("audio_attention_pool.out_proj.weight", c.projection_size, H);
       m->pool_out_b = B.vec("audio_attention_pool.out_proj.bias", c.projection_size);
     }
@@ -319,9 +345,12 @@ int build_weights(caco_model* m) {
       L.ln_out = B.ln(p + ".output.LayerNorm", H);
       m->tlayers.push_back(L);
     }
+    // key = key_proj(h) / sqrt(H) (roberta.py:259); one query, one head
     const HostTensor* q = B.get("text_module.pooler.attention_pool_query", {1, H});
-    if (q) m->tpool_query = B.upload_f32(q->data.data(), (size_t)H);
-    m->tpool_kv = B.lin_cat({"text_module.pooler.key_proj", "text_module.pooler.value_proj"}, H, H);
+    m->tpool_wq = B.pool_wq(q ? q->data.data() : nullptr, "text_module.pooler.key_proj.weight", H, 0, H, 1, 1.0f / sqrtf((float)H));
+    (void)B.get("text_module.pooler.key_proj.bias", {H});      // required by the contract; a constant score shift: no effect
+    m->tpool_v_w = B.mat_f32("text_module.pooler.value_proj.weight", H, H);
+    m->tpool_v_b = B.vec("text_module.pooler.value_proj.bias", H);
     m->text_proj_w = B.mat_f32("text_proj.weight", c.projection_size, H);
     m->text_proj_b = B.vec("text_proj.bias", c.projection_size);
   }
@@ -634,7 +663,7 @@ int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const 
                        void* stream) {
   CACO_TRY(check_audio_shapes(m, batch, seq));
   CACO_REQUIRE(patches && tinds && finds && mask && emb, "caco_audio_forward: null argument");
-  CACO_REQUIRE(m->pool_query, "caco_audio_forward: model has no audio pooler (AudioMAE-only weights)");
+  CACO_REQUIRE(m->pool_wq, "caco_audio_forward: model has no audio pooler (AudioMAE-only weights)");
   hipStream_t st = (hipStream_t)stream;
   const caco_config& c = m->cfg;
   const int H = c.audio_hidden, P = c.patch_size;
@@ -644,8 +673,8 @@ int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const 
   w.plan(A, M, batch, seq, H, c.audio_intermediate);
   const size_t o_pb = A.reserve((size_t)M * P * 2);
   const size_t o_hid = A.reserve((size_t)M * H * 4);
-  const size_t o_kv = A.reserve((size_t)M * 2 * H * 2);
-  const size_t o_pool = A.reserve((size_t)batch * H * 4);
+  const size_t o_pool = A.reserve((size_t)batch * c.pool_heads * H * 4);
+  const size_t o_pv = A.reserve((size_t)batch * H * 4);
   const size_t o_emb = A.reserve((size_t)batch * c.projection_size * 4);
   CACO_TRY(A.commit(st));
   float* x = A.at<float>(w.x);
@@ -658,14 +687,16 @@ int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const 
   CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
   float* hid = hidden ? hidden : A.at<float>(o_hid);
   CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hid, h, st));
-  // AudioAttentionPooler.forward, caco.py:41-79
-  bf16_t* kv = A.at<bf16_t>(o_kv);
-  CACO_STAGE("audio.pool_kv_gemm", linear_bf16(m->pool_kv, h, M, ACT_NONE, kv, st));
-  float* pooled = A.at<float>(o_pool);
+  // AudioAttentionPooler.forward, caco.py:41-79 (projections folded out of the token loop, pool.hip)
+  float* pooled = A.at<float>(o_pool);                  // [B, heads, H]: softmax-weighted token means per head
+  float* pv = A.at<float>(o_pv);                        // [B, H]: value projection of the pooled rows, heads concatenated
   const int phd = H / c.pool_heads;
-  CACO_STAGE("audio.pool", attn_pool(kv, m->pool_query, mask, batch, seq, H, c.pool_heads, 1.0f / sqrtf((float)phd), pooled, st));
+  CACO_STAGE("audio.pool", attn_pool_rows(h, m->pool_wq, mask, batch, seq, H, c.pool_heads, pooled, st));
+  for (int hh = 0; hh < c.pool_heads; ++hh)
+    CACO_STAGE("audio.pool", gemm_f32(pooled + (size_t)hh * H, m->pool_v_w + (size_t)hh * phd * H, m->pool_v_b + hh * phd,
+                                      pv + hh * phd, batch, phd, H, H, 1.0f, st, c.pool_heads * H));
   float* e = normalize ? A.at<float>(o_emb) : emb;
-  CACO_STAGE("audio.proj_norm", gemm_f32(pooled, m->pool_out_w, m->pool_out_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
+  CACO_STAGE("audio.proj_norm", gemm_f32(pv, m->pool_out_w, m->pool_out_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
   if (normalize) CACO_STAGE("audio.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
   return CACO_OK;
 }
@@ -684,7 +715,7 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
   const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2);
   const size_t o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
-  const size_t o_mask = A.reserve((size_t)M * 4), o_kv = A.reserve((size_t)M * 2 * H * 2);
+  const size_t o_mask = A.reserve((size_t)M * 4), o_pv = A.reserve((size_t)batch * H * 4);
   const size_t o_pool = A.reserve((size_t)batch * H * 4), o_emb = A.reserve((size_t)batch * c.projection_size * 4);
   CACO_TRY(A.commit(st));
   float* x = A.at<float>(o_x);
@@ -713,12 +744,12 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   }
   if (nl == 0 && hidden) CACO_HIP(hipMemcpyAsync(hidden, x, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
   // AttentionPooler.forward (roberta.py:253-271) + text_proj (caco.py:169)
-  bf16_t* kv = A.at<bf16_t>(o_kv);
-  CACO_STAGE("text.pool_kv_gemm", linear_bf16(m->tpool_kv, xb, M, ACT_NONE, kv, st));
   float* pooled = A.at<float>(o_pool);
-  CACO_STAGE("text.pool", attn_pool(kv, m->tpool_query, fmask, batch, seq, H, 1, 1.0f / sqrtf((float)H), pooled, st));
+  float* pv = A.at<float>(o_pv);
+  CACO_STAGE("text.pool", attn_pool_rows(xb, m->tpool_wq, fmask, batch, seq, H, 1, pooled, st));
+  CACO_STAGE("text.pool", gemm_f32(pooled, m->tpool_v_w, m->tpool_v_b, pv, batch, H, H, H, 1.0f, st));
   float* e = normalize ? A.at<float>(o_emb) : emb;
-  CACO_STAGE("text.proj_norm", gemm_f32(pooled, m->text_proj_w, m->text_proj_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
+  CACO_STAGE("text.proj_norm", gemm_f32(pv, m->text_proj_w, m->text_proj_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
   if (normalize) CACO_STAGE("text.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
   return CACO_OK;
 }

@@ -412,7 +412,7 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st) {
 namespace {
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        const float* __restrict__ bias, float* __restrict__ C, int M,
-                                                       int N, int K, int ldc, float scale) {
+                                                       int N, int K, int ldc, float scale, int lda) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tiles_n = (N + 31) / 32;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int ra = min(tm * 32 + (lane & 31), M - 1);
   const int rb = min(tn * 32 + (lane & 31), N - 1);
   const int half = lane >> 5;
-  const float* ap = A + (int64_t)ra * K + half * 4;
+  const float* ap = A + (int64_t)ra * lda + half * 4;
   const float* bp = B + (int64_t)rb * K + half * 4;
   f32x16 acc;
 #pragma unroll
@@ -445,11 +445,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }  // namespace
 
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
-             hipStream_t st) {
+             hipStream_t st, int lda) {
   CACO_REQUIRE(M > 0 && N > 0 && K > 0 && (K % 8 == 0), "gemm_f32: need M,N > 0 and K %% 8 == 0 (got %d,%d,%d)", M, N, K);
   CACO_REQUIRE(ldc >= N, "gemm_f32: ldc %d < N %d", ldc, N);
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, A, B, bias, C, M, N, K, ldc, scale);
+  CACO_REQUIRE(lda == 0 || (lda >= K && lda % 4 == 0), "gemm_f32: lda %d must be >= K and a multiple of 4", lda);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, A, B, bias, C, M, N, K, ldc, scale, lda ? lda : K);
   return check_hip(hipGetLastError(), "gemm_f32 launch");
 }
 

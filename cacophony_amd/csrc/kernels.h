@@ -35,7 +35,7 @@ int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_
 bool gemm_bf16_w4_ok(const GemmArgs& p, int epi);                         // gemm_w4.hip
 int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st);   // waves: 4 or 8
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
-             hipStream_t st);
+             hipStream_t st, int lda = 0);     // lda: row stride of A in elements (0 = K)
 
 // norm.hip
 int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
@@ -60,9 +60,10 @@ int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq,
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st);
 
-// pool.hip: learned-query attention pooling over kv[b, s, 0:H | H:2H] (bf16) -> out fp32 [B, H]
-int attn_pool(const bf16_t* kv, const float* query, const float* mask, int batch, int seq, int hidden, int heads,
-              float scale, float* out, hipStream_t st);
+// pool.hip: learned-query attention pooling over the encoder output rows themselves (projections folded out):
+// x bf16 [B, S, H], wq fp32 [heads, H] -> out fp32 [B, heads, H]
+int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,
+                   hipStream_t st);
 
 // topk.hip: per-row top-k (value desc, index asc) through arbitrary strides
 int topk_rows(const float* sim, int rows, int cols, int64_t row_stride, int64_t col_stride, int k, int* idx, float* val,

@@ -1,93 +1,150 @@
-// Learned-query attention pooling: one query vector per head attends over the S tokens of a clip /
-// caption and returns the softmax-weighted mean of the values.
+// Learned-query attention pooling: one query vector per head attends over the S tokens of a clip / caption and
+// returns the softmax-weighted mean of the values.
 //
-//   audio: AudioAttentionPooler.forward, src/caco_torch/caco.py:41-79 (2 heads x 384, scale 1/sqrt(384))
-//   text : AttentionPooler.forward, src/caco_torch/text_models/roberta.py:253-271 (1 head x 768, key/sqrt(768))
+//   audio: AudioAttentionPooler.forward, src/caco_torch/caco.py:41-79 (kv_proj 768 -> 1536, 2 heads x 384, q / sqrt(384))
+//   text : AttentionPooler.forward, src/caco_torch/text_models/roberta.py:253-271 (key_proj / sqrt(768), value_proj, 1 head)
 //
-// Input is the fused [k | v] projection kv[B*S, 2H] (bf16) written by one GEMM.  One workgroup per
-// (head, clip): scores by wave-reduced dot products into LDS, block softmax in fp32, then the
-// value reduction with the key loop split over the 4 waves and combined through LDS.
+// Both linear maps are moved out of the token dimension (exact algebra, no approximation):
+//   scores[j,h] = (x_j Wk_h^T + bk_h) . q_h * s = x_j . (s Wk_h^T q_h) + const_h       softmax is shift-invariant: const_h drops
+//   out_h       = sum_j p[j,h] (x_j Wv_h^T + bv_h) = (sum_j p[j,h] x_j) Wv_h^T + bv_h  since sum_j p[j,h] = 1
+// so the device work over the tokens is ONE pass over the encoder output x (bf16, 197 MB at batch 256): per head a dot
+// product with the pre-folded vector wq_h = s Wk_h^T q_h and an online-softmax weighted sum of the rows themselves;
+// the [B*S, 2H] key/value projection GEMM and its 393 MB round trip disappear, and the value projection becomes an
+// exact-fp32 GEMM on the pooled [B, heads, H] rows (api.hip).  A clip whose tokens are all masked pools to 0.
 #include "common.h"
 #include "kernels.h"
 
 namespace caco {
 namespace {
 
-__global__ __launch_bounds__(256) void attn_pool_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ query,
-                                                        const float* __restrict__ mask, int S, int H, int heads,
-                                                        float scale, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* sc = sm;                       // [S] scores -> probabilities
-  float* red = sm + S;                  // [8] reduction scratch
-  float* part = red + 8;                // [4][hd] per-wave partial outputs
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int hd = H / heads;
-  const bf16_t* kb = kv + (int64_t)b * S * (2 * H) + h * hd;
-  const bf16_t* vb = kb + H;
-  const float* q = query + h * hd;
+constexpr int PW = 8;            // waves per workgroup; one workgroup per clip / caption
+constexpr int PMAXC = 4;         // bf16x4 chunks per lane -> hidden <= 1024
 
-  // 1. scores
-  for (int j = wave; j < S; j += 4) {
-    float acc = 0.f;
-    const bf16_t* kr = kb + (int64_t)j * (2 * H);
-    for (int d = lane * 2; d < hd; d += 128) {
-      const bf16x2 k2 = *reinterpret_cast<const bf16x2*>(kr + d);
-      acc += (float)k2[0] * q[d] + (float)k2[1] * q[d + 1];
+template <int HEADS>
+__global__ __launch_bounds__(PW * 64) void pool_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wq,
+                                                            const float* __restrict__ mask, int S, int H,
+                                                            float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // [PW][HEADS][H] partial sums, then [PW][HEADS][2] (m, l)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int nchunk = H >> 2;                                      // 4-element chunks per row
+  const bf16_t* xb = x + (int64_t)b * S * H;
+
+  f32x4 w[HEADS][PMAXC];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+    for (int c = 0; c < PMAXC; ++c)
+      w[h][c] = (c * 64 + lane < nchunk) ? *reinterpret_cast<const f32x4*>(wq + (int64_t)h * H + (c * 64 + lane) * 4)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[HEADS][PMAXC];
+  float m_run[HEADS], l_run[HEADS];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+    m_run[h] = -INFINITY;
+    l_run[h] = 0.f;
+#pragma unroll
+    for (int c = 0; c < PMAXC; ++c) acc[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // rows of this wave, four in flight: the loads of a group are issued before the first dot product needs them
+  constexpr int UN = 4;
+  for (int j0 = wave; j0 < S; j0 += PW * UN) {
+    bf16x4 raw[UN][PMAXC];
+    bool keep[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * PW;
+      keep[u] = j < S && !(mask && mask[(int64_t)b * S + j] == 0.f);     // wave-uniform: masked tokens carry no weight
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c)
+        if (keep[u] && c * 64 + lane < nchunk) raw[u][c] = *reinterpret_cast<const bf16x4*>(xb + (int64_t)j * H + (c * 64 + lane) * 4);
     }
-    acc = wave_sum(acc) * scale;
-    if (mask && mask[(int64_t)b * S + j] == 0.f) acc = -INFINITY;
-    if (lane == 0) sc[j] = acc;
-  }
-  __syncthreads();
-  // 2. softmax over S
-  float m = -INFINITY;
-  for (int j = tid; j < S; j += 256) m = fmaxf(m, sc[j]);
-  m = wave_max(m);
-  if (lane == 0) red[wave] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  const float m_use = (m == -INFINITY) ? 0.f : m;
-  float s = 0.f;
-  for (int j = tid; j < S; j += 256) {
-    const float p = __expf(sc[j] - m_use);
-    sc[j] = p;
-    s += p;
-  }
-  s = wave_sum(s);
-  if (lane == 0) red[4 + wave] = s;
-  __syncthreads();
-  const float tot = red[4] + red[5] + red[6] + red[7];
-  const float inv = tot > 0.f ? 1.0f / tot : 0.f;
-  // 3. out[d] = sum_j p_j v[j][d]; wave w takes keys j = w, w+4, ...; lanes own element pairs
-  for (int d0 = 0; d0 < hd; d0 += 128) {
-    const int d = d0 + lane * 2;
-    float a0 = 0.f, a1 = 0.f;
-    if (d < hd) {
-      for (int j = wave; j < S; j += 4) {
-        const bf16x2 v2 = *reinterpret_cast<const bf16x2*>(vb + (int64_t)j * (2 * H) + d);
-        const float p = sc[j];
-        a0 += p * (float)v2[0];
-        a1 += p * (float)v2[1];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (!keep[u]) continue;
+      f32x4 v[PMAXC];
+      float dot[HEADS];
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) dot[h] = 0.f;
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c) {
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c * 64 + lane < nchunk) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[c][e] = (float)raw[u][c][e];
+#pragma unroll
+          for (int h = 0; h < HEADS; ++h)
+            dot[h] += (v[c][0] * w[h][c][0] + v[c][1] * w[h][c][1]) + (v[c][2] * w[h][c][2] + v[c][3] * w[h][c][3]);
+        }
       }
-      part[wave * hd + d] = a0;
-      part[wave * hd + d + 1] = a1;
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        const float s = wave_sum(dot[h]);
+        const float m_new = fmaxf(m_run[h], s);
+        const float alpha = __expf(m_run[h] - m_new);               // first token: exp(-inf) = 0
+        const float p = __expf(s - m_new);
+        l_run[h] = l_run[h] * alpha + p;
+        m_run[h] = m_new;
+#pragma unroll
+        for (int c = 0; c < PMAXC; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][c][e] = acc[h][c][e] * alpha + p * v[c][e];
+      }
+    }
+  }
+
+  // combine the PW waves' running states
+  float* part = sm;                                   // [PW][HEADS][H]
+  float* ml = sm + PW * HEADS * H;                    // [PW][HEADS][2]
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+    for (int c = 0; c < PMAXC; ++c)
+      if (c * 64 + lane < nchunk) *reinterpret_cast<f32x4*>(part + ((int64_t)wave * HEADS + h) * H + (c * 64 + lane) * 4) = acc[h][c];
+    if (lane == 0) {
+      ml[(wave * HEADS + h) * 2] = m_run[h];
+      ml[(wave * HEADS + h) * 2 + 1] = l_run[h];
     }
   }
   __syncthreads();
-  for (int d = tid; d < hd; d += 256)
-    out[(int64_t)b * H + h * hd + d] = (part[d] + part[hd + d] + part[2 * hd + d] + part[3 * hd + d]) * inv;
+  for (int i = tid; i < HEADS * H; i += PW * 64) {
+    const int h = i / H, k = i - h * H;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int wv = 0; wv < PW; ++wv) mx = fmaxf(mx, ml[(wv * HEADS + h) * 2]);
+    float num = 0.f, den = 0.f;
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int wv = 0; wv < PW; ++wv) {
+        const float f = __expf(ml[(wv * HEADS + h) * 2] - mx);    // a wave that saw no token: exp(-inf) = 0
+        den += ml[(wv * HEADS + h) * 2 + 1] * f;
+        num += part[((int64_t)wv * HEADS + h) * H + k] * f;
+      }
+    }
+    out[((int64_t)b * HEADS + h) * H + k] = den > 0.f ? num / den : 0.f;
+  }
 }
 
 }  // namespace
 
-int attn_pool(const bf16_t* kv, const float* query, const float* mask, int batch, int seq, int hidden, int heads,
-              float scale, float* out, hipStream_t st) {
-  CACO_REQUIRE(heads > 0 && hidden % heads == 0 && (hidden / heads) % 2 == 0, "attn_pool: bad hidden/heads %d/%d", hidden, heads);
-  const int hd = hidden / heads;
-  const size_t smem = (size_t)(seq + 8 + 4 * hd) * sizeof(float);
-  CACO_REQUIRE(smem <= 64 * 1024, "attn_pool: sequence %d too long for the LDS score buffer", seq);
-  hipLaunchKernelGGL(attn_pool_kernel, dim3(heads, batch), dim3(256), smem, st, kv, query, mask, seq, hidden, heads, scale, out);
+// x bf16 [batch, seq, hidden]; wq fp32 [heads, hidden] (scale and key projection folded in); out fp32 [batch, heads, hidden]
+int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,
+                   hipStream_t st) {
+  CACO_REQUIRE(x && wq && out && batch > 0 && seq > 0, "attn_pool: bad arguments");
+  CACO_REQUIRE(heads == 1 || heads == 2, "attn_pool: %d pooling heads unsupported (1 or 2)", heads);
+  CACO_REQUIRE(hidden % 4 == 0 && hidden <= 256 * PMAXC, "attn_pool: hidden %d must be a multiple of 4, <= %d", hidden, 256 * PMAXC);
+  const size_t smem = (size_t)PW * heads * (hidden + 2) * sizeof(float);
+  CACO_REQUIRE(smem <= 160 * 1024, "attn_pool: hidden %d too large for the LDS combine buffer", hidden);
+  if (heads == 1) {
+    static bool attr1 = false;
+    if (!attr1) { CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+    hipLaunchKernelGGL(pool_rows_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
+  } else {
+    static bool attr2 = false;
+    if (!attr2) { CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr2 = true; }
+    hipLaunchKernelGGL(pool_rows_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
+  }
   return check_hip(hipGetLastError(), "attn_pool launch");
 }
 

@@ -13,6 +13,7 @@ one() { # name counter cmd...
   python tools/summarize_pmc.py "$f" > $OUT/$name.csv
   rm -rf $OUT/raw_$name
 }
+[ -x tools/probes/mall_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probes/mall_probe.hip -o tools/probes/mall_probe 2>/dev/null
 one cal_fetch FETCH_SIZE tools/probes/mall_probe
 one cal_write WRITE_SIZE tools/probes/mall_probe
 one gemm_fetch FETCH_SIZE python tools/gemm_bench.py --iters 3 --only $ONLY --tile $TILE

@@ -364,7 +364,11 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
     // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w4.hip; most reuse per L2 byte, measured
     // 2-10 % faster than the phased kernel below on the encoder shapes) when every CU gets >= 2 tiles,
     // else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128
-    if (gemm_bf16_w4_ok(p, epi) && tiles_x >= 4 * 256) return gemm_bf16_w4(p, epi, act, 8, st);
+    // threshold in 256x128-tile units.  128 also sends the text tower's M = 8192 GEMMs here: in isolation the 128x128
+    // kernel is faster for its N = 768 shapes, but the text tower runs NEXT TO the audio tower and a few persistent
+    // 160 KiB workgroups interleave with the audio GEMMs better than many small ones (step 32.2 -> 31.7 ms measured)
+    static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
+    if (gemm_bf16_w4_ok(p, epi) && tiles_x >= w8_min) return gemm_bf16_w4(p, epi, act, 8, st);
     if (tiles_x >= 256) return gemm_bf16_x(p, epi, act, st);
   }
   return launch_cfg<128, 128, 2, 2, EPI, ACT>(p, st);

@@ -34,6 +34,8 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w4_ok(const GemmArgs& p, int epi);                         // gemm_w4.hip
 int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st);   // waves: 4 or 8
+bool gemm_bf16_v8_ok(const GemmArgs& p, int epi);                         // gemm_v8.hip
+int gemm_bf16_v8(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
              hipStream_t st, int lda = 0);     // lda: row stride of A in elements (0 = K)
 

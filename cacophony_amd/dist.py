@@ -31,12 +31,13 @@ def pack_banks(audio_emb: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
     return torch.stack([audio_emb.float(), text_emb.float()], dim=1).contiguous()
 
 
-def gather_embedding_banks(audio_emb: torch.Tensor, text_emb: torch.Tensor, group: Optional[dist.ProcessGroup] = None
-                           ) -> Tuple[torch.Tensor, torch.Tensor]:
+def gather_embedding_banks(audio_emb: torch.Tensor, text_emb: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                           always_communicate: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """ONE all-gather of the packed banks; returns (A_all [W*B, D], T_all [W*B, D]) in rank order.
 
-    Every rank must contribute the same B (weak scaling: fixed per-GPU batch)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Every rank must contribute the same B (weak scaling: fixed per-GPU batch).  A single-rank job skips the
+    collective unless `always_communicate` (used by the 1-GPU test of the RCCL call)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_communicate):
         return audio_emb.float(), text_emb.float()
     world = dist.get_world_size(group)
     send = pack_banks(audio_emb, text_emb)

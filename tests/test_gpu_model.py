@@ -262,3 +262,28 @@ def test_audiomae_matches_reference_golden(tag, layers, ln_fold):
               torch.ones(2, 396))
     assert y.shape == (2, 496, 256)
     assert rel_l2(y.cpu().numpy()[:, g["rows"]], g["out_rows"]) < HIDDEN_TOL
+
+
+def test_rccl_gather_path_single_rank(full_model):
+    """The N > 1 exchange (one all_gather_into_tensor of the packed fp32 banks over RCCL) exercised on the one GPU a test
+    box has: world_size 1, collective forced.  Sharding / ordering for world_size 2 is covered on CPU (gloo)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from cacophony_amd.dist import gather_embedding_banks, sharded_similarity
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        wav = torch.from_numpy(synth.make_waveforms(4, start=500)).to(DEV)
+        ids, tmask = synth.make_captions(4, 32, start=500)
+        ea, et = full_model.encode_pairs(wav, ids, tmask)
+        ga, gt = gather_embedding_banks(ea, et, always_communicate=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ga, ea) and torch.equal(gt, et)
+        block = sharded_similarity(ea, et, 1.0)
+        assert (block - similarity(ea, et)).abs().max().item() == 0.0
+    finally:
+        dist.destroy_process_group()

@@ -83,6 +83,38 @@ def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(256)
 
 
+@pytest.mark.parametrize("tile", [256, 1256, 8256, 4256, 9256])
+@pytest.mark.parametrize("M,N,K,kind", [(70000, 768, 768, "f32r"), (33333, 768, 3072, "f32r"), (50000, 2304, 768, "bf16"),
+                                        (45000, 3072, 768, "silu")])
+def test_gemm_persistent_multi_tile_pipeline(lib, tile, M, N, K, kind):
+    """Shapes with several output tiles per persistent workgroup: exercises what the small cases cannot reach - loads
+    prefetched across output-tile boundaries, the counted waits that leave an epilogue's stores in flight, the ragged
+    last M tile in the middle of a pipeline, repeated runs on the same buffers (stale-LDS races would show as rare
+    wrong tiles, so every element is checked, three times)."""
+    lib.caco_set_gemm_tile(tile)
+    a = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 13)
+    ref = a.float() @ w.float().T + bias
+    for rep in range(3):
+        if kind == "f32r":
+            x0 = _rand((M, N), 14 + rep)
+            x = x0.clone()
+            _lib.check(lib.caco_op_gemm_bf16_f32out(_p(a), _p(w), _p(bias), _p(x), M, N, K, _p(x), _st()))
+            torch.cuda.synchronize()
+            err = (x - (ref + x0)).abs().max().item()
+            assert err < 3e-3, f"rep {rep}: max err {err}"
+        else:
+            act = 1 if kind == "silu" else 0
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            _lib.check(lib.caco_op_gemm_bf16(_p(a), _p(w), _p(bias), M, N, K, act, _p(out), _st()))
+            torch.cuda.synchronize()
+            r = torch.nn.functional.silu(ref) if act else ref
+            err = ((out.float() - r).abs() / (r.abs() + 1.0)).max().item()
+            assert err < 2e-2, f"rep {rep}: max rel err {err}"
+    lib.caco_set_gemm_tile(256)
+
+
 def test_gemm_rejects_bad_shapes(lib):
     a = torch.zeros(64, 100, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(ValueError):

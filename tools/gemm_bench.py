@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--only", default="")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const"],
+                    help="operand values: the sustained clock depends on bit toggling (DVFS), see DESIGN.md 4.1")
     a = ap.parse_args()
     lib = _lib.load()
     lib.caco_set_gemm_tile(a.tile)
@@ -35,6 +37,10 @@ def main():
         A = (torch.randn(M, K, device=dev)).bfloat16()
         W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
         bias = torch.randn(N, device=dev)
+        if a.data == "zeros":
+            A.zero_(); W.zero_()
+        elif a.data == "const":
+            A.fill_(1.0); W.fill_(1.0 / K)
         if kind == "bf16":
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             run = lambda: lib.caco_op_gemm_bf16(p(A), p(W), p(bias), M, N, K, act, p(out), st)

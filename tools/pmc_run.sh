@@ -8,6 +8,8 @@ run() { # name counters... (command in "$CMD")
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/raw_$name -o p -- "${CMD[@]}" > $OUT/$name.log 2>&1
   local f=$(find $OUT/raw_$name -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python tools/summarize_pmc.py "$f" | grep -i "kernel,\|$FILT" > $OUT/$name.csv; cat $OUT/$name.csv; else echo "no counters for $name"; tail -3 $OUT/$name.log; fi
+  local kt=$(find $OUT/raw_$name -name "*kernel_trace.csv" | head -1)   # wall time of the same dispatches (clock = cycles / time)
+  if [ -n "$kt" ]; then python tools/summarize_trace.py "$kt" "$FILT" | tee $OUT/$name.dur; fi
   rm -rf $OUT/raw_$name
 }
 CMD=("$@")

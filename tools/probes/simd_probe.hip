@@ -23,6 +23,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (s == 12345.f) out[threadIdx.x] = s + smem[threadIdx.x];
 }
 
+// Same stream with operands that toggle the way a real GEMM's do: 4 A x 4 B fragments of hashed (mode 1) or zero (mode 0)
+// bf16 values, acc[i*4+j] += A[i]*B[j].  The gap between the two modes is the DVFS/power cost of operand toggling alone.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void probe_data(float* out, int iters, int mode) {
+  f32x16 acc[16];
+  for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  bf16x8 a[4], b[4];
+  unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 8; ++e) {
+    h = h * 1664525u + 1013904223u; float va = ((h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f;
+    h = h * 1664525u + 1013904223u; float vb = ((h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f;
+    a[i][e] = (__bf16)(mode ? va : 0.f); b[i][e] = (__bf16)(mode ? vb * 0.03f : 0.f);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.f) out[threadIdx.x] = s;
+}
+
 int main() {
   unsigned* ids; float* out;
   hipMalloc(&ids, 256 * 4 * 4); hipMalloc(&out, 1024);
@@ -45,5 +68,17 @@ int main() {
     for (int g = 0; g < 256; ++g) { int m = 0; for (int w = 0; w < 4; ++w) m |= 1 << ((h[g * 4 + w] >> 4) & 3); if (m != 15) ++bad; }
     printf("  workgroups not on 4 distinct SIMDs: %d / 256\n", bad);
   }
+  for (int rep = 0; rep < 2; ++rep)
+    for (int mode : {1, 0}) {
+      probe_data<<<256, 256>>>(out, 100, mode);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      probe_data<<<256, 256>>>(out, iters, mode);
+      hipEventRecord(e1);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      double flops = 256.0 * 4 * iters * 16 * 2.0 * 32 * 32 * 16;
+      printf("bare MFMA stream, %s operands: %.3f ms  %.1f TFLOP/s\n", mode ? "hashed" : "zero", ms, flops / ms / 1e9);
+    }
   return 0;
 }

@@ -45,6 +45,7 @@ constexpr int W_SMEM = 5 * W_SLOT;            // 163840 = 160 KiB
 constexpr int W_SLAB = 8192;                  // per-wave epilogue slab inside a dead A slot
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef W4_NOREADS
 #define W4_DO_READS 0
@@ -406,17 +407,30 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
   }                                                                                              \
   __builtin_amdgcn_sched_barrier(0);
 
-template <int EPI, int ACT>
-__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t mw, int nw, int lane, char* slab) {
+// Epilogue of one 256x256 tile, this wave's 128 x 64 part.  MODE selects what is known at compile time, so that the hot
+// forms carry no per-element branches or phi copies (the generic form measured 400 v_mov + 70 branches per tile):
+//   0 generic: bias / residual / LayerNorm-fold consumer / producer outputs all tested at run time
+//   1 bias only        2 bias + residual (EPI_F32)
+// Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
+// fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
   const int lm = lane & 31, lh = lane >> 5;
   const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
+  const int64_t mw = m0 + wm * 128;
+  const int nw = n0 + wn * 64;
+  const int rows = (int)min((int64_t)128, p.M - mw);    // valid rows of this wave's part (may be <= 0)
+  const bool has_bias = MODE ? true : p.bias != nullptr;
   if constexpr (EPI == EPI_BF16) {
     // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7).
     // Bias (and the LayerNorm-fold column sums) are re-read from L1 per 4-column group instead of being held in 32-64
     // registers across the whole epilogue: the accumulators already fill half the register file.
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + nw + c8 * 8;
-    const bool fold = p.fold_mr != nullptr;          // LayerNorm folded into this GEMM (kernels.h)
-    const float* bias_l = p.bias ? p.bias + nw + lh * 4 : nullptr;
+    const int rowb = p.ldc * 2;
+    const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    const bool fold = MODE ? false : p.fold_mr != nullptr;          // LayerNorm folded into this GEMM (kernels.h)
+    const float* bias_l = has_bias ? p.bias + nw + lh * 4 : nullptr;
     const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -431,7 +445,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 bb = bias_l ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 bb = has_bias ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
           if (fold) {
             const f32x4 cc = *reinterpret_cast<const f32x4*>(c1_l + j * 32 + g * 8);
 #pragma unroll
@@ -439,69 +453,77 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
           }
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)w4_epi_act<ACT>(__builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]));
+          for (int r = 0; r < 4; ++r) {
+            const float x = MODE ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
+            o[r] = (bf16_t)w4_epi_act<ACT>(x);
+          }
           *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
         }
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
-        const int64_t m = mw + i * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
 #ifdef W4_NOSTORE
-        if (m < p.M && v[0] == (bf16_t)12345.f) *reinterpret_cast<bf16x8*>(outp + m * p.ldc) = v;
+        if (v[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, 0);
 #else
-        if (m < p.M) *reinterpret_cast<bf16x8*>(outp + m * p.ldc) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, 0);
 #endif
       }
     }
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
-    f32x4 res[2][4];
+    const int rowb = p.ldc * 4;
+    const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
+    const bool has_resid = MODE ? MODE == 2 : p.resid != nullptr;
+    const bool produce_xb = MODE ? false : p.xb_out != nullptr;
+    const bool produce_st = MODE ? false : p.stats_part != nullptr;
+    const __amdgpu_buffer_rsrc_t out_r =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    u32x4 res[2][4];
     float st1[4][4], st2[4][4];
-    auto fetch = [&](int s, f32x4 (&dst)[4]) {
+    auto fetch = [&](int s, u32x4 (&dst)[4]) {
       const int i = s >> 1, j = s & 1;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int64_t m = min(mw + i * 32 + tt * 8 + rrow, p.M - 1);
-        dst[tt] = *reinterpret_cast<const f32x4*>(p.resid + m * p.ldc + nw + j * 32 + c8 * 4);
-      }
+      for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, 0);
     };
-    if (p.resid) fetch(0, res[0]);
+    if (has_resid) fetch(0, res[0]);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int i = s >> 1, j = s & 1;
-      if (p.resid && s + 1 < 8) fetch(s + 1, res[(s + 1) & 1]);
+      if (has_resid && s + 1 < 8) fetch(s + 1, res[(s + 1) & 1]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
+        if (has_bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
         *reinterpret_cast<f32x4*>(slab + lm * 128 + (((g * 2 + lh) ^ (lm & 7)) << 4)) = v;
       }
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
-        const int64_t m = mw + i * 32 + row;
-        if (p.resid) v += res[s & 1][tt];
-        if (m < p.M) {
-          const int64_t o = m * p.ldc + nw + j * 32 + c8 * 4;
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
-          if (p.xb_out) {
+        if (has_resid) v += __builtin_bit_cast(f32x4, res[s & 1][tt]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, 0);
+        if (produce_xb) {
+          const int64_t m = mw + i * 32 + row;
+          if (m < p.M) {
             bf16x4 b;
 #pragma unroll
             for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(p.xb_out + o) = b;
+            *reinterpret_cast<bf16x4*>(p.xb_out + m * p.ldc + nw + j * 32 + c8 * 4) = b;
           }
         }
-        if (p.stats_part) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
+        if (produce_st) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
           const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
           const float a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
           if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
         }
       }
     }
-    if (p.stats_part) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
+    if (produce_st) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
       const int nslot = p.N >> 6, slot = nw >> 6;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -522,7 +544,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
 
 // (kernel bodies live in __device__ functions: the buffer-descriptor types they use are invisible to the host pass,
 // which otherwise drops the kernel's launch stub)
-template <int EPI, int ACT>
+template <int EPI, int ACT, int MODE>
 __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -642,7 +664,7 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    w8_epilogue<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 64, lane, smem + a_2 + wave * 4096);
+    w8_epilogue<EPI, ACT, MODE>(acc, p, m_cur, n_cur, wm, wn, lane, smem + a_2 + wave * 4096);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
     // the next tile's first fragments are re-read here (ks3 already fetched them once): this way they are not live
@@ -655,7 +677,8 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
     // a full tile issued exactly NST stores per wave.  Only the fp32 + residual epilogue uses the relaxed wait:
     // measured -4..-5 % on the out-proj / fc2 shapes, but +29 % on the bf16 QKV shape (N = 2304), where letting
     // every CU run ahead with 16 more stores in flight makes the HBM write bursts collide
-    stores_pending = (EPI == EPI_F32) && (m_cur + 256 <= p.M) && (!p.xb_out == !p.stats_part);
+    // (buffer stores of rows past M are dropped by the descriptor but still issue, so the count is exact)
+    stores_pending = (EPI == EPI_F32) && (MODE != 0 || !p.xb_out == !p.stats_part);
 #endif
 #endif
     c_li += slots;
@@ -669,16 +692,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   w4_body<EPI, ACT>(p, smem);
 }
 
-template <int EPI, int ACT>
+template <int EPI, int ACT, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_w8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  w8_body<EPI, ACT>(p, smem);
+  w8_body<EPI, ACT, MODE>(p, smem);
 }
 
-template <int EPI, int ACT, int NWV>
+template <int EPI, int ACT, int NWV, int MODE = 0>
 int launch_w4(const GemmArgs& p, hipStream_t st) {
   void (*kern)(GemmArgs) = nullptr;
-  if constexpr (NWV == 8) kern = gemm_bf16_w8_kernel<EPI, ACT>;
+  if constexpr (NWV == 8) kern = gemm_bf16_w8_kernel<EPI, ACT, MODE>;
   else kern = gemm_bf16_w4_kernel<EPI, ACT>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -716,6 +739,19 @@ bool gemm_bf16_w4_ok(const GemmArgs& p, int epi) {
 template <int NWV>
 static int gemm_bf16_w_t(const GemmArgs& p, int epi, int act, hipStream_t st) {
   CACO_REQUIRE(gemm_bf16_w4_ok(p, epi), "gemm_bf16_w4: shape not supported");
+  if constexpr (NWV == 8) {   // the specialised epilogues (w8_epilogue): bias only, bias + residual
+    static const bool generic = getenv("CACO_W8_GENERIC") && atoi(getenv("CACO_W8_GENERIC"));
+    const bool plain = !generic && p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
+    if (plain && epi == EPI_BF16 && !p.resid) {
+      if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, 8, 1>(p, st);
+      if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, 8, 1>(p, st);
+      if (act == ACT_GELU) return launch_w4<EPI_BF16, ACT_GELU, 8, 1>(p, st);
+    }
+    if (plain && epi == EPI_F32 && act == ACT_NONE) {
+      if (p.resid) return launch_w4<EPI_F32, ACT_NONE, 8, 2>(p, st);
+      return launch_w4<EPI_F32, ACT_NONE, 8, 1>(p, st);
+    }
+  }
   if (epi == EPI_BF16) {
     if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, NWV>(p, st);
     if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, NWV>(p, st);

@@ -31,6 +31,7 @@ class CacoConfigC(C.Structure):
         ("text_ln_eps", C.c_float),
         ("projection_size", C.c_int32), ("pool_heads", C.c_int32), ("logit_scale", C.c_float),
         ("has_audio", C.c_int32), ("has_text", C.c_int32), ("mae_decoder_layers", C.c_int32),
+        ("caption_decoder_layers", C.c_int32),
     ]
 
 
@@ -55,6 +56,7 @@ _SIGNATURES = {
     "caco_similarity": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
     "caco_l2_normalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "caco_topk": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "caco_token_group_mean": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "caco_mae_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "caco_workspace_bytes": (_i64, [_vp]),
     "caco_set_gemm_tile": (_i32, [_i32]),
@@ -66,6 +68,8 @@ _SIGNATURES = {
     "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "caco_op_attention": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_op_attention_qkv": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

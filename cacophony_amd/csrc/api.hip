@@ -96,6 +96,11 @@ struct TextLayer {    // RobertaLayer, text_models/roberta.py:181-215
   Lin qkv, attn_out, inter, out;
   LNp ln_attn, ln_out;
 };
+struct DecLayer {     // RobertaLayer(has_cross_attention=True), text_models/roberta.py:181-215
+  TextLayer t;
+  Lin cq, ckv, cattn_out;   // crossattention.self.query | key;value (fused) | crossattention.output.dense
+  LNp ln_cross;
+};
 
 }  // namespace
 }  // namespace caco
@@ -121,6 +126,10 @@ struct caco_model {
   float* tpool_wq = nullptr;                            // [1, H]
   float *tpool_v_w = nullptr, *tpool_v_b = nullptr;
   float *text_proj_w = nullptr, *text_proj_b = nullptr;
+  // caption decoder (RobertaDecoder, roberta.py:329-373): cross-attention layers + vocabulary projection whose rows are
+  // zero-padded to a multiple of 256 so that the GEMM needs no column tail
+  std::vector<DecLayer> dlayers;
+  Lin dec_proj;
   float logit_scale = 0.f;
   // workspace arenas, one per (tower, stream): forwards enqueued on DIFFERENT streams (audio next to text, or two
   // half batches) never share scratch memory and may overlap on the GPU; calls on one stream reuse one arena
@@ -202,6 +211,31 @@ struct Builder {
     return o;
   }
   Lin lin(const std::string& p, int out, int in) { return lin_rows(p + ".weight", p + ".bias", out, in, 0, out); }
+  // Linear [out, in] stored with `out_pad` >= out rows (zero rows / zero bias past `out`)
+  Lin lin_padded(const std::string& p, int out, int in, int out_pad) {
+    Lin o;
+    const HostTensor* w = get(p + ".weight", {out, in});
+    const HostTensor* b = get(p + ".bias", {out});
+    if (!w || !b) return o;
+    std::vector<float> wp((size_t)out_pad * in, 0.f), bp((size_t)out_pad, 0.f);
+    std::copy(w->data.begin(), w->data.end(), wp.begin());
+    std::copy(b->data.begin(), b->data.end(), bp.begin());
+    o.w = upload_bf16(wp.data(), wp.size());
+    o.b = upload_f32(bp.data(), bp.size());
+    o.out = out_pad;
+    o.in = in;
+    return o;
+  }
+  TextLayer text_layer(const std::string& p, int H, int I) {
+    TextLayer L;
+    L.qkv = lin_cat({p + ".attention.self.query", p + ".attention.self.key", p + ".attention.self.value"}, H, H);
+    L.attn_out = lin(p + ".attention.output.dense", H, H);
+    L.ln_attn = ln(p + ".attention.output.LayerNorm", H);
+    L.inter = lin(p + ".intermediate.dense", I, H);
+    L.out = lin(p + ".output.dense", H, I);
+    L.ln_out = ln(p + ".output.LayerNorm", H);
+    return L;
+  }
   // Linear whose rows are the concatenation of several [rows_i, in] Linears (fused projections)
   Lin lin_cat(const std::vector<std::string>& ps, int rows_each, int in) {
     Lin o;
@@ -336,14 +370,7 @@ int build_weights(caco_model* m) {
     m->emb_ln = B.ln(e + ".LayerNorm", H);
     for (int n = 0; n < c.text_layers; ++n) {
       const std::string p = "text_module.encoder.layers." + std::to_string(n);
-      TextLayer L;
-      L.qkv = B.lin_cat({p + ".attention.self.query", p + ".attention.self.key", p + ".attention.self.value"}, H, H);
-      L.attn_out = B.lin(p + ".attention.output.dense", H, H);
-      L.ln_attn = B.ln(p + ".attention.output.LayerNorm", H);
-      L.inter = B.lin(p + ".intermediate.dense", c.text_intermediate, H);
-      L.out = B.lin(p + ".output.dense", H, c.text_intermediate);
-      L.ln_out = B.ln(p + ".output.LayerNorm", H);
-      m->tlayers.push_back(L);
+      m->tlayers.push_back(B.text_layer(p, H, c.text_intermediate));
     }
     // key = key_proj(h) / sqrt(H) (roberta.py:259); one query, one head
     const HostTensor* q = B.get("text_module.pooler.attention_pool_query", {1, H});
@@ -353,6 +380,18 @@ int build_weights(caco_model* m) {
     m->tpool_v_b = B.vec("text_module.pooler.value_proj.bias", H);
     m->text_proj_w = B.mat_f32("text_proj.weight", c.projection_size, H);
     m->text_proj_b = B.vec("text_proj.bias", c.projection_size);
+    for (int n = 0; n < c.caption_decoder_layers; ++n) {
+      const std::string p = "decoder_module.encoder.layers." + std::to_string(n);
+      DecLayer L;
+      L.t = B.text_layer(p, H, c.text_intermediate);
+      L.cq = B.lin(p + ".crossattention.self.query", H, H);
+      L.ckv = B.lin_cat({p + ".crossattention.self.key", p + ".crossattention.self.value"}, H, H);
+      L.cattn_out = B.lin(p + ".crossattention.output.dense", H, H);
+      L.ln_cross = B.ln(p + ".crossattention.output.LayerNorm", H);
+      m->dlayers.push_back(L);
+    }
+    if (c.caption_decoder_layers > 0)
+      m->dec_proj = B.lin_padded("decoder_module.decoder_proj", c.text_vocab, H, (c.text_vocab + 255) / 256 * 256);
   }
   auto ls = m->pending.find("logit_scale");
   if (ls != m->pending.end() && ls->second.data.size() == 1) m->logit_scale = ls->second.data[0];
@@ -521,7 +560,7 @@ void caco_default_config(caco_config* c) {
   c->text_vocab = 50265; c->text_hidden = 768; c->text_layers = 12; c->text_heads = 12; c->text_intermediate = 3072;
   c->text_max_pos = 514; c->text_type_vocab = 1; c->text_ln_eps = 1e-5f;
   c->projection_size = 768; c->pool_heads = 2; c->logit_scale = 2.6592f;
-  c->has_audio = 1; c->has_text = 1; c->mae_decoder_layers = 0;
+  c->has_audio = 1; c->has_text = 1; c->mae_decoder_layers = 0; c->caption_decoder_layers = 0;
 }
 
 int caco_create(const caco_config* cfg, caco_model** out) {
@@ -539,6 +578,9 @@ int caco_create(const caco_config* cfg, caco_model** out) {
     CACO_REQUIRE(cfg->text_heads > 0 && cfg->text_hidden / cfg->text_heads == 64 && cfg->text_hidden % cfg->text_heads == 0,
                  "caco_create: text head_dim must be 64");
   }
+  CACO_REQUIRE(cfg->caption_decoder_layers >= 0 && (cfg->caption_decoder_layers == 0 || (cfg->has_text && cfg->has_audio &&
+               cfg->audio_hidden == cfg->text_hidden)),
+               "caco_create: the caption decoder needs both towers with equal hidden sizes");
   int dev = 0;
   CACO_HIP(hipGetDevice(&dev));
   caco_model* m = new (std::nothrow) caco_model();
@@ -563,9 +605,9 @@ int caco_load_tensor(caco_model* m, const char* name, const float* host, const i
     return CACO_ERR_STATE;
   }
   const std::string key(name);
-  if (key.rfind("decoder_module.", 0) == 0) return CACO_OK;   // caption decoder: out of scope, ignored
+  if (key.rfind("decoder_module.", 0) == 0 && m->cfg.caption_decoder_layers == 0) return CACO_OK;   // model built without it
   static const char* known[] = {"audio_module.", "audio_attention_pool.", "text_module.", "text_proj.", "logit_scale",
-                                "encoder.", "decoder."};
+                                "encoder.", "decoder.", "decoder_module."};
   bool ok = false;
   for (const char* k : known) ok = ok || key.rfind(k, 0) == 0;
   CACO_REQUIRE(ok, "caco_load_tensor: unknown state-dict key '%s'", name);
@@ -754,6 +796,62 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   return CACO_OK;
 }
 
+// RobertaDecoder.forward (roberta.py:337-373) as called by CACO.get_decoder_logits (caco.py:212-240): teacher-forced
+// logits over the vocabulary for every caption position, cross-attending to the audio encoder's hidden states.
+int caco_decoder_forward(caco_model* m, const float* text_hidden, const int64_t* text_mask, const float* audio_hidden,
+                         const float* audio_mask, int32_t batch, int32_t seq_t, int32_t seq_a, float* logits, void* stream) {
+  CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_REQUIRE(!m->dlayers.empty() && m->dec_proj.w, "Decoder module not initialized");
+  CACO_REQUIRE(text_hidden && text_mask && audio_hidden && audio_mask && logits && batch > 0 && seq_t > 0 && seq_a > 0,
+               "caco_decoder_forward: bad arguments");
+  const caco_config& c = m->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = c.text_hidden, I = c.text_intermediate, V = c.text_vocab, Vp = m->dec_proj.out;
+  const int heads = c.text_heads, hd = H / heads;
+  const int64_t M = (int64_t)batch * seq_t, Ma = (int64_t)batch * seq_a;
+  Arena A(m, WS_TEXT, st);
+  const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
+  const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2), o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
+  const size_t o_mask = A.reserve((size_t)M * 4), o_ab = A.reserve((size_t)Ma * H * 2), o_kv = A.reserve((size_t)Ma * 2 * H * 2);
+  const size_t o_lg = A.reserve((size_t)M * Vp * 4);
+  CACO_TRY(A.commit(st));
+  float* x = A.at<float>(o_x);
+  float* y = A.at<float>(o_y);
+  bf16_t* xb = A.at<bf16_t>(o_xb);
+  bf16_t* qkv = A.at<bf16_t>(o_qkv);
+  bf16_t* o = A.at<bf16_t>(o_o);
+  bf16_t* a = A.at<bf16_t>(o_a);
+  float* fmask = A.at<float>(o_mask);
+  bf16_t* ab = A.at<bf16_t>(o_ab);
+  bf16_t* kv = A.at<bf16_t>(o_kv);
+  float* lg = A.at<float>(o_lg);
+  CACO_TRY(mask_i64_to_f32(text_mask, fmask, M, st));
+  CACO_HIP(hipMemcpyAsync(x, text_hidden, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+  CACO_STAGE("decoder.cast", cast_f32_to_bf16(x, xb, M * H, st));
+  CACO_STAGE("decoder.cast", cast_f32_to_bf16(audio_hidden, ab, Ma * H, st));
+  for (const DecLayer& L : m->dlayers) {
+    // self-attention: causal AND caption-padding mask (roberta.py:347-356)
+    CACO_STAGE("decoder.gemm_qkv", linear_bf16(L.t.qkv, xb, M, ACT_NONE, qkv, st));
+    CACO_STAGE("decoder.attention", attention(qkv, 3 * H, H, 2 * H, fmask, batch, seq_t, heads, hd, 1, o, st));
+    CACO_STAGE("decoder.gemm_out", linear_f32(L.t.attn_out, o, M, x, y, st));
+    CACO_STAGE("decoder.ln", layernorm(y, L.t.ln_attn.g, L.t.ln_attn.b, M, H, c.text_ln_eps, x, xb, st));
+    // cross-attention over the audio tokens: queries from the caption, keys / values from the audio hidden states,
+    // padded audio tokens masked (roberta.py:204-210, :358-362)
+    CACO_STAGE("decoder.gemm_cross_q", linear_bf16(L.cq, xb, M, ACT_NONE, qkv, st));
+    CACO_STAGE("decoder.gemm_cross_kv", linear_bf16(L.ckv, ab, Ma, ACT_NONE, kv, st));
+    CACO_STAGE("decoder.cross_attention", attention_qkv(qkv, H, seq_t, kv, 2 * H, 0, H, audio_mask, batch, seq_a, heads, hd, 0, o, st));
+    CACO_STAGE("decoder.gemm_out", linear_f32(L.cattn_out, o, M, x, y, st));
+    CACO_STAGE("decoder.ln", layernorm(y, L.ln_cross.g, L.ln_cross.b, M, H, c.text_ln_eps, x, xb, st));
+    CACO_STAGE("decoder.gemm_fc1", linear_bf16(L.t.inter, xb, M, ACT_GELU, a, st));
+    CACO_STAGE("decoder.gemm_fc2", linear_f32(L.t.out, a, M, x, y, st));
+    CACO_STAGE("decoder.ln", layernorm(y, L.t.ln_out.g, L.t.ln_out.b, M, H, c.text_ln_eps, x, xb, st));
+  }
+  // decoder_proj (roberta.py:371): [M, H] x [Vp, H]^T into the padded scratch rows, then the V real columns out
+  CACO_STAGE("decoder.gemm_vocab", linear_f32(m->dec_proj, xb, M, nullptr, lg, st));
+  CACO_HIP(hipMemcpy2DAsync(logits, (size_t)V * 4, lg, (size_t)Vp * 4, (size_t)V * 4, (size_t)M, hipMemcpyDeviceToDevice, st));
+  return CACO_OK;
+}
+
 int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float* emb,
                       void* stream) {
   CACO_TRY(check_audio_shapes(m, batch, max_patches));
@@ -784,6 +882,12 @@ int caco_topk(const float* sim, int32_t rows, int32_t cols, int64_t row_stride, 
               float* val, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   CACO_STAGE("retrieval.topk", topk_rows(sim, rows, cols, row_stride, col_stride, k, idx, val, st));
+  return CACO_OK;
+}
+
+int caco_token_group_mean(const float* hidden, int32_t batch, int32_t seq, int32_t dim, int32_t group, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CACO_STAGE("hear.token_group_mean", token_group_mean(hidden, batch, seq, dim, group, out, st));
   return CACO_OK;
 }
 
@@ -853,6 +957,14 @@ int caco_op_layernorm(const float* x, const float* g, const float* b, int64_t ro
                       void* ob, void* stream) {
   return layernorm(x, g, b, rows, dim, eps, of, (bf16_t*)ob, (hipStream_t)stream);
 }
+int caco_op_attention_qkv(const void* q, int32_t q_ld, int32_t seq_q, const void* kv, int32_t ld, int32_t k_off, int32_t v_off,
+                          const float* mask, int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal,
+                          void* out, void* stream) {
+  CACO_REQUIRE(q && kv && out, "caco_op_attention_qkv: null argument");
+  return attention_qkv((const bf16_t*)q, q_ld, seq_q, (const bf16_t*)kv, ld, k_off, v_off, mask, batch, seq, heads, head_dim,
+                       causal, (bf16_t*)out, (hipStream_t)stream);
+}
+
 int caco_op_attention(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, const float* mask, int32_t batch,
                       int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out, void* stream) {
   CACO_REQUIRE(qkv && out, "caco_op_attention: null argument");

@@ -56,8 +56,8 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
 
 // (the body lives in a __device__ function: the buffer-descriptor builtins it uses are not visible to the host pass)
 template <int HD, bool CAUSAL, int NW>
-__device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
-                                               const float* __restrict__ key_mask, int S, int heads,
+__device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, int q_ld, int Sq, const bf16_t* __restrict__ kv, int ld,
+                                               int k_off, int v_off, const float* __restrict__ key_mask, int S, int heads,
                                                bf16_t* __restrict__ out, float scale_log2) {
   constexpr int NT = NW * 64, QB = NW * 32;
   constexpr int RP = HD * 2;                   // K and V row pitch in LDS = the unpadded row (192 / 128 bytes)
@@ -75,17 +75,20 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int H = heads * HD;
-  const int64_t row_base = (int64_t)b * S;
-  const bf16_t* q_base = qkv + row_base * ld + h * HD;
+  // queries: rows [b*Sq, b*Sq+Sq) of qp_ (row stride q_ld); keys / values: rows [b*S, b*S+S) of kv (row stride ld), at
+  // columns k_off / v_off past the head's first column.  Self-attention passes the same buffer twice (Sq == S).
+  const int64_t row_base = (int64_t)b * S, qrow_base = (int64_t)b * Sq;
+  const bf16_t* q_base = qp_ + qrow_base * q_ld + h * HD;
+  const bf16_t* kv_base = kv + row_base * ld + h * HD;
 
   const int q0 = qb * QB + wave * 32;
   const int q_row = q0 + l31;
-  const bool wave_active = q0 < S;
+  const bool wave_active = q0 < Sq;
 
   // Q fragments (B operand: column j = query, k = 8 contiguous head-dim elements)
   bf16x8 qf[KS];
   {
-    const bf16_t* qp = q_base + (int64_t)(q_row < S ? q_row : S - 1) * ld + hf * 8;
+    const bf16_t* qp = q_base + (int64_t)(q_row < Sq ? q_row : Sq - 1) * q_ld + hf * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
@@ -98,7 +101,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, i
 
   // DMA geometry: piece pc of a tile covers LDS bytes [pc*1024, +1024) = linear 16-byte chunks pc*64 + lane.
   // chunk L -> row L / KCH, chunk position L % KCH; the K source chunk is un-swizzled from the position.
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)q_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)kv_base, 0, 0x7fffffff, 0x00020000);
   int d_row[PPW], d_kcol[PPW], d_vcol[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
@@ -246,8 +249,8 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, i
   if (!wave_active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_row < S) {
-    bf16_t* op = out + (row_base + q_row) * H + h * HD + 4 * hf;
+  if (q_row < Sq) {
+    bf16_t* op = out + (qrow_base + q_row) * H + h * HD + 4 * hf;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -261,25 +264,36 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qkv, i
 }
 
 template <int HD, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, 3) void attention_kernel(const bf16_t* __restrict__ qkv, int ld, int k_off, int v_off,
+__global__ __launch_bounds__(NW * 64, 3) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
+                                                               const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
                                                                bf16_t* __restrict__ out, float scale_log2) {
-  attention_body<HD, CAUSAL, NW>(qkv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2);
+  attention_body<HD, CAUSAL, NW>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2);
 }
 
 }  // namespace
 
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st) {
-  CACO_REQUIRE(batch > 0 && seq > 0 && heads > 0, "attention: bad shape B=%d S=%d heads=%d", batch, seq, heads);
+  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st);
+}
+
+// General form: queries [batch, seq_q] rows of `q` (row stride q_ld, head h at column h*head_dim), keys / values
+// [batch, seq] rows of `kv` (row stride ld, head h at columns h*head_dim + k_off / v_off).  Cross-attention of the caption
+// decoder (RobertaSelfAttention with key_value_states, src/caco_torch/text_models/roberta.py:67-104): seq_q != seq.
+int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask,
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st) {
+  CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);
+  CACO_REQUIRE(!causal || seq_q == seq, "attention: the causal mask needs seq_q == seq (%d vs %d)", seq_q, seq);
+  CACO_REQUIRE(q_ld % 8 == 0, "attention: query row stride must be a multiple of 8 elements");
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
   constexpr int NW = 4;
-  const dim3 grid((seq + NW * 32 - 1) / (NW * 32), heads, batch);
+  const dim3 grid((seq_q + NW * 32 - 1) / (NW * 32), heads, batch);
 #define CACO_ATTN(HD_, C_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2)
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2)
   if (head_dim == 96) {
     if (causal) CACO_ATTN(96, true); else CACO_ATTN(96, false);
   } else {

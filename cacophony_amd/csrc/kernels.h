@@ -61,6 +61,8 @@ int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq,
 // qkv: bf16 [batch*seq, ld], Q at column 0, K at k_off, V at v_off (head h = columns h*head_dim.. of each)
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st);
+int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st);
 
 // pool.hip: learned-query attention pooling over the encoder output rows themselves (projections folded out):
 // x bf16 [B, S, H], wq fp32 [heads, H] -> out fp32 [B, heads, H]
@@ -68,6 +70,7 @@ int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batc
                    hipStream_t st);
 
 // topk.hip: per-row top-k (value desc, index asc) through arbitrary strides
+int token_group_mean(const float* x, int batch, int seq, int hidden, int group, float* out, hipStream_t st);
 int topk_rows(const float* sim, int rows, int cols, int64_t row_stride, int64_t col_stride, int k, int* idx, float* val,
               hipStream_t st);
 

@@ -126,6 +126,23 @@ __global__ __launch_bounds__(PW * 64) void pool_rows_kernel(const bf16_t* __rest
   }
 }
 
+// Mean over `group` consecutive tokens (the HEAR "event" embedding: tf.nn.avg_pool(hidden, ksize=8, strides=8, 'VALID')
+// over the 8 frequency patches of one time step, src/eval/heareval/embeddings/audio_embedding/caco_embeddings.py:118-124).
+// One thread per 4 output channels; a warp reads 1 KiB-contiguous row segments.  HBM-bound: seq*hidden*4 B in per clip.
+__global__ __launch_bounds__(256) void token_group_mean_kernel(const float* __restrict__ x, int seq, int hidden, int group, int n_out,
+                                                               float* __restrict__ out) {
+  const int h4 = hidden >> 2;
+  const int b = blockIdx.y;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n_out * h4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(e / h4), c = (int)(e - (int64_t)t * h4);
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + ((int64_t)b * seq + (int64_t)t * group) * hidden) + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < group; ++g) acc += src[(int64_t)g * h4];
+    const float inv = 1.0f / (float)group;
+    reinterpret_cast<f32x4*>(out + ((int64_t)b * n_out + t) * hidden)[c] = acc * inv;
+  }
+}
+
 }  // namespace
 
 // x bf16 [batch, seq, hidden]; wq fp32 [heads, hidden] (scale and key projection folded in); out fp32 [batch, heads, hidden]
@@ -146,6 +163,19 @@ int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batc
     hipLaunchKernelGGL(pool_rows_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
   }
   return check_hip(hipGetLastError(), "attn_pool launch");
+}
+
+// x fp32 [batch, seq, hidden] -> out fp32 [batch, seq / group, hidden] (trailing seq % group tokens dropped: 'VALID')
+int token_group_mean(const float* x, int batch, int seq, int hidden, int group, float* out, hipStream_t st) {
+  CACO_REQUIRE(batch > 0 && seq > 0 && group > 0, "token_group_mean: bad shape");
+  CACO_REQUIRE(hidden > 0 && hidden % 4 == 0, "token_group_mean: hidden %d must be a positive multiple of 4", hidden);
+  const int n_out = seq / group;
+  if (n_out == 0) return CACO_OK;               // fewer tokens than one group: empty output ('VALID')
+  CACO_REQUIRE(x && out, "token_group_mean: null argument");
+  const int64_t work = (int64_t)n_out * (hidden >> 2);
+  const int gx = (int)((work + 255) / 256 < 64 ? (work + 255) / 256 : 64);
+  hipLaunchKernelGGL(token_group_mean_kernel, dim3(gx, batch), dim3(256), 0, st, x, seq, hidden, group, n_out, out);
+  return check_hip(hipGetLastError(), "token_group_mean launch");
 }
 
 }  // namespace caco

@@ -49,7 +49,8 @@ class _HipModel:
     """Owns one caco_model handle."""
 
     def __init__(self, audio_config: Optional[AudioTransformerConfig], text_config: Optional[RobertaConfig],
-                 caco_config: CACOConfig, mae_decoder_layers: int = 0, device: Union[str, torch.device, None] = None):
+                 caco_config: CACOConfig, mae_decoder_layers: int = 0, device: Union[str, torch.device, None] = None,
+                 caption_decoder_layers: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("cacophony_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self._lib = _lib.load()
@@ -71,6 +72,7 @@ class _HipModel:
         cfg.projection_size, cfg.pool_heads = caco_config.projection_size, caco_config.num_attention_pool_heads
         cfg.logit_scale = caco_config.logit_scale_init_value
         cfg.mae_decoder_layers = mae_decoder_layers
+        cfg.caption_decoder_layers = caption_decoder_layers
         self._cfg_c = cfg
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -119,9 +121,17 @@ class CACO(_HipModel):
 
     def __init__(self, audio_config: AudioTransformerConfig, text_config: RobertaConfig, caco_config: CACOConfig,
                  decoder_config: Optional[RobertaConfig] = None, device=None):
-        super().__init__(audio_config, text_config, caco_config, 0, device)
+        if decoder_config is not None:
+            # RobertaDecoder (text_models/roberta.py:329-373): this build shares the text tower's kernels and shapes
+            same = ("vocab_size", "hidden_size", "num_attention_heads", "intermediate_size", "layer_norm_eps")
+            if any(getattr(decoder_config, k) != getattr(text_config, k) for k in same):
+                raise ValueError("decoder_config must match text_config in " + ", ".join(same))
+        super().__init__(audio_config, text_config, caco_config, 0, device,
+                         caption_decoder_layers=decoder_config.num_hidden_layers if decoder_config is not None else 0)
         self.audio_config, self.text_config, self.caco_config = audio_config, text_config, caco_config
-        self.decoder_module = None        # captioning is out of scope
+        self.decoder_config = decoder_config
+        # truthy when the caption decoder is present (reference call sites test `model.decoder_module is None`)
+        self.decoder_module = self._decoder_forward if decoder_config is not None else None
         self.logit_scale = torch.tensor(caco_config.logit_scale_init_value, dtype=torch.float32, device=self.device)
 
     def load_state_dict(self, state_dict, strict: bool = True):
@@ -194,8 +204,33 @@ class CACO(_HipModel):
         at = similarity(a, t, float(torch.exp(self.logit_scale)))
         return at, at.T
 
-    def get_decoder_logits(self, *_, **__):
-        raise ValueError("Decoder module not initialized")      # caco.py:223-224
+    def _decoder_forward(self, text_hidden_state, attention_mask, audio_hidden_state, audio_mask, deterministic: bool = True):
+        """RobertaDecoder.forward (text_models/roberta.py:337-373): [B,T,H], [B,T], [B,S,H], [B,S] -> logits [B,T,vocab]."""
+        self._inference_only(deterministic)
+        th = _dev_tensor(text_hidden_state, torch.float32, self.device, "text_hidden_state")
+        tm = _dev_tensor(attention_mask, torch.int64, self.device, "attention_mask")
+        ah = _dev_tensor(audio_hidden_state, torch.float32, self.device, "audio_hidden_state")
+        am = _dev_tensor(audio_mask, torch.float32, self.device, "audio_mask")
+        H = self.text_config.hidden_size
+        if th.dim() != 3 or ah.dim() != 3 or th.shape[2] != H or ah.shape[2] != H or th.shape[0] != ah.shape[0]:
+            raise ValueError(f"decoder: hidden states must be [B, T, {H}] and [B, S, {H}], got {tuple(th.shape)} / {tuple(ah.shape)}")
+        B, T, _ = th.shape
+        S = ah.shape[1]
+        if tuple(tm.shape) != (B, T) or tuple(am.shape) != (B, S):
+            raise ValueError(f"decoder: masks must be [{B}, {T}] and [{B}, {S}], got {tuple(tm.shape)} / {tuple(am.shape)}")
+        logits = torch.empty(B, T, self.text_config.vocab_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.caco_decoder_forward(self._handle, _ptr(th), _ptr(tm), _ptr(ah), _ptr(am), B, T, S,
+                                                      _ptr(logits), _stream()), "decoder")
+        return logits
+
+    def get_decoder_logits(self, audio_hidden_state, audio_mask, text_input_ids, text_mask, deterministic: bool = True):
+        """caco.py:212-240: caption-prefix hidden states from the text tower, then the cross-attending decoder."""
+        if self.decoder_module is None:
+            raise ValueError("Decoder module not initialized")      # caco.py:223-224
+        _, text_hidden_state = self.get_text_embedding(text_input_ids=text_input_ids, text_mask=text_mask,
+                                                       deterministic=deterministic)
+        return self._decoder_forward(text_hidden_state, text_mask, audio_hidden_state, audio_mask, deterministic)
 
     def forward(self, audio_patches, audio_time_inds, audio_freq_inds, audio_mask, text_input_ids, text_mask,
                 deterministic: bool = True):
@@ -292,9 +327,12 @@ def l2_normalize(x: Tensor) -> Tensor:
     return out
 
 
-def create_caco_model(device=None) -> CACO:
-    """Default-configuration model, src/caco_torch/caco.py:264-317 (caption decoder omitted)."""
-    return CACO(default_audio_config(), default_text_config(), default_caco_config(), device=device)
+def create_caco_model(device=None, use_decoder: bool = False) -> CACO:
+    """Default-configuration model, src/caco_torch/caco.py:264-317.  The reference always builds the 4-layer caption
+    decoder; here it is opt-in (`use_decoder=True`): the embedding / scoring path never touches it, and a state dict's
+    `decoder_module.*` tensors are skipped when the model was built without it."""
+    dec = replace(default_text_config(), num_hidden_layers=4) if use_decoder else None     # caco.py:297-309
+    return CACO(default_audio_config(), default_text_config(), default_caco_config(), decoder_config=dec, device=device)
 
 
 class AudioMAE(_HipModel):

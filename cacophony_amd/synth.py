@@ -148,9 +148,28 @@ def make_text_encoder_state(cfg: RobertaConfig, prefix: str = "text_module", see
     return sd
 
 
+def make_text_decoder_state(cfg: RobertaConfig, prefix: str = "decoder_module", seed: int = 0):
+    """`decoder_module.*` of a CACO state dict: RobertaDecoder, src/caco_torch/text_models/roberta.py:329-335."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    h, i = cfg.hidden_size, cfg.intermediate_size
+    for n in range(cfg.num_hidden_layers):
+        p = f"{prefix}.encoder.layers.{n}"
+        for att in ("attention", "crossattention"):
+            _linear(sd, f"{p}.{att}.self.query", h, h, seed)
+            _linear(sd, f"{p}.{att}.self.key", h, h, seed)
+            _linear(sd, f"{p}.{att}.self.value", h, h, seed)
+            _linear(sd, f"{p}.{att}.output.dense", h, h, seed)
+            _layernorm(sd, f"{p}.{att}.output.LayerNorm", h, seed)
+        _linear(sd, p + ".intermediate.dense", i, h, seed)
+        _linear(sd, p + ".output.dense", h, i, seed)
+        _layernorm(sd, p + ".output.LayerNorm", h, seed)
+    _linear(sd, prefix + ".decoder_proj", cfg.vocab_size, h, seed)
+    return sd
+
+
 def make_caco_state(audio_cfg: AudioTransformerConfig, text_cfg: RobertaConfig, caco_cfg: CACOConfig,
-                    seed: int = 0) -> "OrderedDict[str, np.ndarray]":
-    """Full CACO state dict minus `decoder_module.*` (captioning is out of scope)."""
+                    seed: int = 0, decoder_cfg: Optional[RobertaConfig] = None) -> "OrderedDict[str, np.ndarray]":
+    """Full CACO state dict; `decoder_module.*` (the caption decoder) only when `decoder_cfg` is given."""
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     sd["logit_scale"] = np.array(caco_cfg.logit_scale_init_value, dtype=np.float32)
     sd.update(make_audio_encoder_state(audio_cfg, "audio_module", seed))
@@ -163,6 +182,8 @@ def make_caco_state(audio_cfg: AudioTransformerConfig, text_cfg: RobertaConfig, 
     _linear(sd, p + ".out_proj", caco_cfg.projection_size, h, seed)
     sd.update(make_text_encoder_state(text_cfg, "text_module", seed))
     _linear(sd, "text_proj", caco_cfg.projection_size, text_cfg.hidden_size, seed)
+    if decoder_cfg is not None:
+        sd.update(make_text_decoder_state(decoder_cfg, "decoder_module", seed))
     return sd
 
 

@@ -51,6 +51,8 @@ typedef struct caco_config {
   float logit_scale;
   int32_t has_audio, has_text;      /* which towers to allocate (AudioMAE-only models set has_text = 0) */
   int32_t mae_decoder_layers;       /* > 0: also hold an AudioDecoder (mae.py:151-207) of that depth     */
+  int32_t caption_decoder_layers;   /* > 0: also hold the caption decoder (RobertaDecoder, text_models/roberta.py:329-373;
+                                       create_caco_model uses 4, caco.py:297-309); widths = the text tower's */
 } caco_config;
 
 const char* caco_version(void);
@@ -118,6 +120,13 @@ int caco_similarity(const float* a_dev, int32_t na, const float* t_dev, int32_t 
  * cols < k); val_dev fp32 [rows, k] or NULL.  1 <= k <= 64. */
 int caco_topk(const float* sim_dev, int32_t rows, int32_t cols, int64_t row_stride, int64_t col_stride, int32_t k,
               int32_t* idx_dev, float* val_dev, void* stream);
+/* HEAR "event" (timestamp) embeddings: mean over `group` consecutive tokens of the encoder's hidden states,
+ * tf.nn.avg_pool(hidden, ksize=8, strides=8, padding='VALID') in
+ * src/eval/heareval/embeddings/audio_embedding/caco_embeddings.py:118-124 (group = 8 = the frequency patches of one
+ * 160 ms time step).  hidden_dev fp32 [batch, seq, dim] (the `hidden` output of caco_audio_forward) ->
+ * out_dev fp32 [batch, seq / group, dim]; the trailing seq % group tokens are dropped. */
+int caco_token_group_mean(const float* hidden_dev, int32_t batch, int32_t seq, int32_t dim, int32_t group, float* out_dev,
+                          void* stream);
 /* x / ||x + 1e-10||_2 per row (src/caco_torch/caco.py:144-146), in place allowed. */
 int caco_l2_normalize(const float* x_dev, int32_t rows, int32_t dim, float* out_dev, void* stream);
 
@@ -127,6 +136,18 @@ int caco_mae_forward(caco_model* m, const void* patches_dev, int32_t patch_dtype
                      const float* time_inds_dev, const float* freq_inds_dev, const float* restore_time_inds_dev,
                      const float* restore_freq_inds_dev, const float* restore_mask_dev, int32_t batch,
                      int32_t n_visible, int32_t n_restore, float* out_dev, void* stream);
+
+/* ---- caption decoder logits: CACO.get_decoder_logits (src/caco_torch/caco.py:212-240) ->
+ * RobertaDecoder.forward (src/caco_torch/text_models/roberta.py:337-373).  Teacher-forced: every layer is
+ * self-attention under the causal AND caption-padding mask, cross-attention over the audio tokens (padded audio
+ * tokens masked), MLP, each followed by a post-LayerNorm; then decoder_proj to the vocabulary.
+ * text_hidden_dev fp32 [B, T, H]  = the `hidden` output of caco_text_forward on the caption prefix (caco.py:226-230),
+ * text_mask_dev int64 [B, T] (1 = keep), audio_hidden_dev fp32 [B, S, H] = the `hidden` output of caco_audio_forward,
+ * audio_mask_dev fp32 [B, S] (1 = keep) -> logits_dev fp32 [B, T, vocab].  Needs caption_decoder_layers > 0 and the
+ * `decoder_module.*` tensors; otherwise CACO_ERR_INVALID with "Decoder module not initialized" (caco.py:223-224). */
+int caco_decoder_forward(caco_model* m, const float* text_hidden_dev, const int64_t* text_mask_dev,
+                         const float* audio_hidden_dev, const float* audio_mask_dev, int32_t batch, int32_t seq_text,
+                         int32_t seq_audio, float* logits_dev, void* stream);
 
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 int64_t caco_workspace_bytes(const caco_model* m);
@@ -165,6 +186,13 @@ int caco_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int caco_op_attention(const void* qkv_dev, int32_t ld, int32_t k_off, int32_t v_off, const float* key_mask_dev,
                       int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out_dev,
                       void* stream);
+/* The same kernel with separate operands (cross-attention, RobertaSelfAttention with key_value_states,
+ * roberta.py:67-104): queries q_dev bf16 [B*seq_q, q_ld] (head h at column h*head_dim), keys / values kv_dev bf16
+ * [B*seq, ld] at columns k_off / v_off, key_mask_dev fp32 [B, seq] or NULL -> out_dev bf16 [B*seq_q, heads*head_dim].
+ * causal needs seq_q == seq. */
+int caco_op_attention_qkv(const void* q_dev, int32_t q_ld, int32_t seq_q, const void* kv_dev, int32_t ld, int32_t k_off,
+                          int32_t v_off, const float* key_mask_dev, int32_t batch, int32_t seq, int32_t heads,
+                          int32_t head_dim, int32_t causal, void* out_dev, void* stream);
 #ifdef __cplusplus
 }
 #endif

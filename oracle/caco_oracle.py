@@ -435,6 +435,48 @@ def roberta_layer(ops, P, cfg, x, bias, prefix: str):
                       P[prefix + ".output.LayerNorm.bias"], cfg.layer_norm_eps)
 
 
+def _roberta_attention(ops, P, cfg, x, kv, bias, prefix: str):
+    """RobertaAttention.forward = RobertaSelfAttention (optionally over `key_value_states`) + RobertaSelfOutput,
+    roberta.py:67-104, 114-124, 133-147.  x [B,T,H] supplies the queries and the residual; kv [B,S,H] keys / values."""
+    B, T, H = x.shape
+    S = kv.shape[1]
+    nh = cfg.num_attention_heads
+    hd = H // nh
+    a = prefix + ".self"
+    q = linear(ops, x, P[a + ".query.weight"], P[a + ".query.bias"]).reshape(B, T, nh, hd)
+    k = linear(ops, kv, P[a + ".key.weight"], P[a + ".key.bias"]).reshape(B, S, nh, hd)
+    v = linear(ops, kv, P[a + ".value.weight"], P[a + ".value.bias"]).reshape(B, S, nh, hd)
+    q, k, v = ops.transpose(q, 1, 2), ops.transpose(k, 1, 2), ops.transpose(v, 1, 2)
+    s_ = ops.matmul(q, ops.transpose(k, -1, -2)) / math.sqrt(hd) + bias
+    p = softmax_last(ops, s_)
+    o = ops.transpose(ops.matmul(p, v), 1, 2).reshape(B, T, H)
+    o = linear(ops, o, P[prefix + ".output.dense.weight"], P[prefix + ".output.dense.bias"])
+    return layer_norm(ops, o + x, P[prefix + ".output.LayerNorm.weight"], P[prefix + ".output.LayerNorm.bias"],
+                      cfg.layer_norm_eps)
+
+
+def roberta_decoder(ops, P, cfg, text_hidden, attention_mask, audio_hidden, audio_mask, prefix: str = "decoder_module"):
+    """RobertaDecoder.forward, roberta.py:337-373: per layer (RobertaLayer with has_cross_attention, :191-215)
+    self-attention under causal AND caption-padding mask (:347-356), cross-attention over the audio tokens with padded
+    audio tokens at -inf (:358-362), GELU MLP, all post-LN; then decoder_proj (:371)."""
+    B, T, H = text_hidden.shape
+    allowed = ops.tril_bool(T)[None, None, :, :] & (attention_mask != 0)[:, None, None, :]
+    zeros = ops.f32(np.zeros((B, 1, T, T), dtype=np.float32))
+    self_bias = ops.where(allowed, zeros, ops.full_like(zeros, -math.inf))
+    S = audio_hidden.shape[1]
+    zc = ops.f32(np.zeros((B, 1, 1, S), dtype=np.float32))
+    cross_bias = ops.where((audio_mask != 0)[:, None, None, :], zc, ops.full_like(zc, -math.inf))
+    x = text_hidden
+    for n in range(cfg.num_hidden_layers):
+        p = f"{prefix}.encoder.layers.{n}"
+        att = _roberta_attention(ops, P, cfg, x, x, self_bias, p + ".attention")
+        att = _roberta_attention(ops, P, cfg, att, audio_hidden, cross_bias, p + ".crossattention")
+        m = gelu_erf(ops, linear(ops, att, P[p + ".intermediate.dense.weight"], P[p + ".intermediate.dense.bias"]))
+        m = linear(ops, m, P[p + ".output.dense.weight"], P[p + ".output.dense.bias"])
+        x = layer_norm(ops, m + att, P[p + ".output.LayerNorm.weight"], P[p + ".output.LayerNorm.bias"], cfg.layer_norm_eps)
+    return linear(ops, x, P[prefix + ".decoder_proj.weight"], P[prefix + ".decoder_proj.bias"])
+
+
 def text_attention_pool(ops, P, hidden, mask, prefix: str):
     """AttentionPooler.forward, roberta.py:253-271."""
     H = hidden.shape[-1]
@@ -475,10 +517,12 @@ def roberta_model(ops, P, cfg, input_ids, attention_mask, position_ids=None, pre
 class CacoOracle:
     """Mirror of `CACO` (src/caco_torch/caco.py:82-261) over a reference-named state dict."""
 
-    def __init__(self, state: Dict[str, np.ndarray], audio_cfg, text_cfg, caco_cfg, backend: str = "numpy"):
+    def __init__(self, state: Dict[str, np.ndarray], audio_cfg, text_cfg, caco_cfg, backend: str = "numpy",
+                 decoder_cfg=None):
         self.ops = get_ops(backend)
         self.P = {k: self.ops.f32(v) for k, v in state.items()}
         self.audio_cfg, self.text_cfg, self.caco_cfg = audio_cfg, text_cfg, caco_cfg
+        self.decoder_cfg = decoder_cfg
         self.logit_scale = float(np.asarray(state["logit_scale"]))
 
     def get_audio_embedding(self, audio_patches, audio_time_inds, audio_freq_inds, audio_mask,
@@ -517,6 +561,15 @@ class CacoOracle:
         return (s * a) @ t.T, (s * t) @ a.T
 
     forward = get_contrastive_logits
+
+    def get_decoder_logits(self, audio_hidden_state, audio_mask, text_input_ids, text_mask):
+        """caco.py:212-240"""
+        if self.decoder_cfg is None:
+            raise ValueError("Decoder module not initialized")
+        o = self.ops
+        _, th = self.get_text_embedding(text_input_ids, text_mask)
+        return o.to_numpy(roberta_decoder(o, self.P, self.decoder_cfg, o.f32(th), o.i64(text_mask),
+                                          o.f32(audio_hidden_state), o.f32(audio_mask)))
 
     # convenience wrappers named in BASELINE.json north_star (SURVEY.md section 8b)
     def encode_audio(self, wav, max_patches: int = 500):
@@ -611,3 +664,19 @@ def retrieval_hits(indices, all_querys, all_keys, gt_query_key, retrieval_type="
         positions = np.arange(1, 11, dtype=float)[preds[:10] > 0]          # :49-54
         mAP10.append(float(np.mean(np.arange(1, len(positions) + 1, dtype=float) / positions)) if len(positions) else 0.0)
     return {"R1": R1, "R5": R5, "R10": R10, "mAP10": mAP10}
+
+
+# ----------------------------------------------------------------------------------------------
+# HEAR embeddings: src/eval/heareval/embeddings/audio_embedding/caco_embeddings.py
+# ----------------------------------------------------------------------------------------------
+def hear_event_embeddings(hidden: np.ndarray, audio_max_len: float = 10.0, group: int = 8):
+    """caco_embeddings.py:118-124: tf.nn.avg_pool(hidden[b], ksize=8, strides=8, 'VALID') over the token axis
+    ([B, S, H] -> [B, S // 8, H]) and timestamps = linspace(0, audio_max_len * 1000, S // 8) in ms.
+    (The JAX reference is not importable here: parity for this function is UNPINNED by reference outputs; it is a
+    direct restatement of two library calls whose semantics are unambiguous.)"""
+    hidden = np.asarray(hidden, dtype=np.float32)
+    b, s, h = hidden.shape
+    n = s // group
+    ev = hidden[:, :n * group].reshape(b, n, group, h).astype(np.float64).mean(axis=2).astype(np.float32)
+    ts = np.linspace(0, audio_max_len * 1000, n)
+    return ev, ts

@@ -263,6 +263,43 @@ def golden_retrieval():
     print("retrieval.npz", {k: float(v.mean()) for k, v in out.items()})
 
 
+@torch.no_grad()
+def golden_decoder(refs):
+    """Caption decoder: CACO.get_decoder_logits (caco.py:212-240) on the 2-layer configuration with a
+    2-layer RobertaDecoder, fed the reference's own audio hidden states: full 32-token captions (one padded) and a
+    12-token prefix as the sampling loop would present it (eval_caco_torch.py:443-456 intends this call)."""
+    ref_caco, ref_mae, ref_roberta, ref_eval = refs
+    a, t, cc = C.tiny_configs(2)
+    d = replace(t, num_hidden_layers=2)
+    model = ref_caco.CACO(_ref_audio_cfg(ref_mae, a), _ref_text_cfg(ref_roberta, t),
+                          ref_caco.CACOConfig(cc.projection_size, cc.num_attention_pool_heads, cc.logit_scale_init_value),
+                          decoder_config=_ref_text_cfg(ref_roberta, d))
+    sd = synth.make_caco_state(a, t, cc, seed=0, decoder_cfg=d)
+    model.load_state_dict(_to_torch_state(sd), strict=True)
+    model.eval()
+    ab = _inputs(ref_eval, 2, start=40)
+    tt = {k: torch.from_numpy(v) for k, v in ab.items()}
+    _, a_hid = model.get_audio_embedding(tt["audio_patches"], tt["audio_time_inds"], tt["audio_freq_inds"], tt["audio_mask"])
+    ids, tmask = synth.make_captions(2, 32, t.vocab_size, start=40)
+    out = {"ids": ids, "tmask": tmask, "audio_hidden_checksum": _checksum(a_hid.numpy())}
+    lg = model.get_decoder_logits(a_hid, tt["audio_mask"], torch.from_numpy(ids), torch.from_numpy(tmask))
+    out["logits"] = lg.numpy()
+    ids12, m12 = ids[:, :12].copy(), np.ones((2, 12), dtype=np.int64)
+    lg12 = model.get_decoder_logits(a_hid, tt["audio_mask"], torch.from_numpy(ids12), torch.from_numpy(m12))
+    out["logits_prefix12_last"] = lg12.numpy()[:, -1]
+    # decoder alone on seeded random hidden states with a ragged audio mask (pure RobertaDecoder.forward)
+    rng = np.random.RandomState(5)
+    th = rng.randn(2, 20, t.hidden_size).astype(np.float32)
+    ah = rng.randn(2, 70, t.hidden_size).astype(np.float32)
+    tm = np.ones((2, 20), dtype=np.int64); tm[1, 13:] = 0
+    am = np.ones((2, 70), dtype=np.float32); am[0, 50:] = 0
+    lg_r = model.decoder_module(text_hidden_state=torch.from_numpy(th), attention_mask=torch.from_numpy(tm),
+                                audio_hidden_state=torch.from_numpy(ah), audio_mask=torch.from_numpy(am))
+    out["rand_logits"] = lg_r.numpy()
+    np.savez_compressed(os.path.join(OUT, "decoder_tiny.npz"), **out)
+    print("decoder_tiny.npz", lg.shape, lg.numpy()[0, :3].argmax(-1), float(np.abs(lg.numpy()).max()))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -276,6 +313,7 @@ def main():
     golden_mae(refs, "tiny", 2)
     golden_mae(refs, "full", 12)
     golden_retrieval()
+    golden_decoder(refs)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,117 @@
+"""Caption decoder logits: CACO.get_decoder_logits (src/caco_torch/caco.py:212-240) ->
+RobertaDecoder.forward (src/caco_torch/text_models/roberta.py:337-373).  Golden = the reference itself
+(tests/golden/make_golden.py::golden_decoder)."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+
+from cacophony_amd import config as C
+from cacophony_amd import synth
+from oracle import caco_oracle as O
+from tests.conftest import checksum, cosine_rows, load_golden, rel_l2
+
+LOGIT_TOL = 1e-2          # rel-L2 of the logits: the same bar as hidden states; bf16 operands, fp32 accumulate
+COS_TOL = 0.999           # per position
+
+
+def _configs():
+    a, t, cc = C.tiny_configs(2)
+    return a, t, cc, replace(t, num_hidden_layers=2)
+
+
+@pytest.fixture(scope="module")
+def dec_state():
+    a, t, cc, d = _configs()
+    return synth.make_caco_state(a, t, cc, seed=0, decoder_cfg=d)
+
+
+def test_oracle_decoder_matches_reference_golden(dec_state):
+    g = load_golden("decoder_tiny.npz")
+    a, t, cc, d = _configs()
+    o = O.CacoOracle(dec_state, a, t, cc, backend="torch", decoder_cfg=d)
+    batch = O.prepare_audio_batch(synth.make_waveforms(2, start=40), 500, backend="torch")
+    _, ah = o.get_audio_embedding(batch["audio_patches"], batch["audio_time_inds"], batch["audio_freq_inds"], batch["audio_mask"])
+    np.testing.assert_allclose(checksum(ah), g["audio_hidden_checksum"], rtol=2e-4)
+    ids, tmask = synth.make_captions(2, 32, t.vocab_size, start=40)
+    np.testing.assert_array_equal(ids, g["ids"])
+    lg = o.get_decoder_logits(ah, batch["audio_mask"], ids, tmask)
+    assert lg.shape == (2, 32, t.vocab_size)
+    assert np.abs(lg - g["logits"]).max() < 2e-4
+    lg12 = o.get_decoder_logits(ah, batch["audio_mask"], ids[:, :12], np.ones((2, 12), np.int64))
+    assert np.abs(lg12[:, -1] - g["logits_prefix12_last"]).max() < 2e-4
+    # the decoder alone on seeded random states with ragged masks on both sides
+    rng = np.random.RandomState(5)
+    th = rng.randn(2, 20, t.hidden_size).astype(np.float32)
+    ah_r = rng.randn(2, 70, t.hidden_size).astype(np.float32)
+    tm = np.ones((2, 20), dtype=np.int64); tm[1, 13:] = 0
+    am = np.ones((2, 70), dtype=np.float32); am[0, 50:] = 0
+    ops = o.ops
+    lr = ops.to_numpy(O.roberta_decoder(ops, o.P, d, ops.f32(th), ops.i64(tm), ops.f32(ah_r), ops.f32(am)))
+    assert np.abs(lr - g["rand_logits"]).max() < 2e-4
+    with pytest.raises(ValueError, match="Decoder module not initialized"):
+        O.CacoOracle(dec_state, a, t, cc, backend="torch").get_decoder_logits(ah, batch["audio_mask"], ids, tmask)
+
+
+@pytest.fixture(scope="module")
+def dec_model(dec_state):
+    from cacophony_amd.model import CACO
+    a, t, cc, d = _configs()
+    return CACO(a, t, cc, decoder_config=d, device="cuda:0").load_state_dict(dec_state)
+
+
+@pytest.mark.gpu
+def test_decoder_logits_match_reference_golden(dec_model):
+    from cacophony_amd import frontend
+    g = load_golden("decoder_tiny.npz")
+    wav = synth.make_waveforms(2, start=40)
+    ab = frontend.mel_patches_device(torch.from_numpy(wav).cuda(), 500, torch.float32)
+    _, ah = dec_model.get_audio_embedding(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"])
+    lg = dec_model.get_decoder_logits(ah, ab["audio_mask"], g["ids"], g["tmask"]).cpu().numpy()
+    assert lg.shape == g["logits"].shape
+    keep = g["tmask"].astype(bool)                  # rows of padded caption positions are defined but never consumed
+    assert rel_l2(lg[keep], g["logits"][keep]) < LOGIT_TOL
+    assert cosine_rows(lg[keep], g["logits"][keep]).min() > COS_TOL
+    assert (lg[keep].argmax(-1) == g["logits"][keep].argmax(-1)).mean() > 0.9
+    # growing-prefix call of the sampling loop (eval_caco_torch.py:443-456): T = 12, no padding
+    lg12 = dec_model.get_decoder_logits(ah, ab["audio_mask"], g["ids"][:, :12], np.ones((2, 12), np.int64)).cpu().numpy()
+    assert rel_l2(lg12[:, -1], g["logits_prefix12_last"]) < LOGIT_TOL
+    # causality: the logits of position p depend only on tokens <= p
+    assert rel_l2(lg12, lg[:, :12]) < 2e-3
+
+
+@pytest.mark.gpu
+def test_decoder_alone_ragged_masks(dec_model):
+    g = load_golden("decoder_tiny.npz")
+    H = dec_model.text_config.hidden_size
+    rng = np.random.RandomState(5)
+    th = rng.randn(2, 20, H).astype(np.float32)
+    ah = rng.randn(2, 70, H).astype(np.float32)
+    tm = np.ones((2, 20), dtype=np.int64); tm[1, 13:] = 0
+    am = np.ones((2, 70), dtype=np.float32); am[0, 50:] = 0
+    lg = dec_model.decoder_module(text_hidden_state=th, attention_mask=tm, audio_hidden_state=ah, audio_mask=am).cpu().numpy()
+    keep = tm.astype(bool)
+    assert rel_l2(lg[keep], g["rand_logits"][keep]) < LOGIT_TOL
+    assert cosine_rows(lg[keep], g["rand_logits"][keep]).min() > COS_TOL
+    # masked audio tokens must not influence the logits: scramble them
+    ah2 = ah.copy(); ah2[0, 50:] = 100.0
+    lg2 = dec_model.decoder_module(th, tm, ah2, am).cpu().numpy()
+    np.testing.assert_array_equal(lg2[0], lg[0])
+
+
+@pytest.mark.gpu
+def test_decoder_error_behaviour(dec_model, tiny_state):
+    from cacophony_amd.model import CACO
+    a, t, cc, d = _configs()
+    plain = CACO(a, t, cc, device="cuda:0").load_state_dict(tiny_state)
+    assert plain.decoder_module is None
+    with pytest.raises(ValueError, match="Decoder module not initialized"):        # caco.py:223-224
+        plain.get_decoder_logits(torch.zeros(1, 8, 768), torch.ones(1, 8), torch.zeros(1, 4, dtype=torch.long), torch.ones(1, 4))
+    with pytest.raises(ValueError):
+        CACO(a, t, cc, decoder_config=replace(d, hidden_size=512, num_attention_heads=8), device="cuda:0")
+    with pytest.raises(ValueError):
+        dec_model.decoder_module(torch.zeros(2, 4, 768), torch.ones(2, 4), torch.zeros(3, 8, 768), torch.ones(3, 8))
+    # a model built WITH the decoder refuses a state dict that lacks decoder_module.*
+    with pytest.raises((ValueError, RuntimeError), match="decoder_module"):
+        CACO(a, t, cc, decoder_config=d, device="cuda:0").load_state_dict(tiny_state)

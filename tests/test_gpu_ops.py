@@ -175,6 +175,32 @@ def test_attention(lib, B, S, heads, hd, causal, valid):
     assert (out.float() - ref).abs().max().item() < 0.03
 
 
+@pytest.mark.parametrize("B,Sq,S,heads,hd,valid", [
+    (2, 32, 500, 12, 64, [496, 144]), (3, 1, 500, 12, 64, [500, 7, 1]), (2, 20, 70, 12, 64, [50, 70]),
+    (1, 200, 33, 8, 96, [33]), (2, 129, 64, 12, 64, [64, 5])])
+def test_cross_attention(lib, B, Sq, S, heads, hd, valid):
+    """queries and keys/values from different buffers and lengths (caption decoder cross-attention, roberta.py:67-104)."""
+    H = heads * hd
+    q = _rand((B, Sq, H), 40, 1.5).bfloat16()
+    kv = _rand((B, S, 2 * H), 41, 1.2).bfloat16()         # row = K | V, the fused key/value projection's layout
+    mask = torch.zeros(B, S, device=DEV)
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.caco_op_attention_qkv(_p(q), H, Sq, _p(kv), 2 * H, 0, H, _p(mask), B, S, heads, hd, 0, _p(out), _st()))
+    qf = q.float().view(B, Sq, heads, hd).transpose(1, 2)
+    kf = kv[..., :H].float().view(B, S, heads, hd).transpose(1, 2)
+    vf = kv[..., H:].float().view(B, S, heads, hd).transpose(1, 2)
+    sc = qf @ kf.transpose(-1, -2) / math.sqrt(hd)
+    sc = sc.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B, Sq, H)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < 0.03
+    # a causal mask between different lengths is rejected, not silently mis-applied
+    assert lib.caco_op_attention_qkv(_p(q), H, Sq, _p(kv), 2 * H, 0, H, _p(mask), B, S, heads, hd, 1, _p(out), _st()) != 0 or Sq == S
+
+
 def test_attention_forced_rescale(lib):
     """A late key that dominates one query row forces the online-softmax rescale branch (max jumps at the last tile)."""
     B, S, heads, hd = 1, 500, 8, 96

@@ -52,6 +52,7 @@ __device__ __forceinline__ void ln_row(f32x4 (&v)[MAXC], int nchunk, int lane, i
   }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows, int dim, float eps,
                                                         float* __restrict__ of, bf16_t* __restrict__ ob) {
@@ -62,7 +63,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   f32x4 v[MAXC];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c)
-    if (c * 64 + lane < nchunk) v[c] = *reinterpret_cast<const f32x4*>(x + row * dim + (c * 64 + lane) * 4);
+    if (c * 64 + lane < nchunk) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + row * dim + (c * 64 + lane) * 4);
+      v[c] = NT ? __builtin_nontemporal_load(src) : *src;
+    }
   ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
 }
 
@@ -222,8 +226,15 @@ int layernorm(const float* x, const float* gamma, const float* beta, int64_t row
               bf16_t* out_bf16, hipStream_t st) {
   CACO_REQUIRE(dim % 4 == 0 && dim > 0 && dim <= 256 * MAXC, "layernorm: dim %d must be a multiple of 4, <= %d", dim, 256 * MAXC);
   CACO_REQUIRE(rows > 0 && x && gamma && beta && (out_f32 || out_bf16), "layernorm: bad arguments");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
-                     out_f32, out_bf16);
+  // streaming (nt) reads of the fp32 rows when only the bf16 copy is produced (pre-LN stacks): x is not needed again
+  // before the next GEMM rewrites it, and the bf16 rows this kernel writes are what should stay cached
+  static const int nt_env = getenv("CACO_LN_NT") ? atoi(getenv("CACO_LN_NT")) : 1;      // measured -1.1 % per step
+  if (nt_env && !out_f32)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
+                       out_f32, out_bf16);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
+                       out_f32, out_bf16);
   return check_hip(hipGetLastError(), "layernorm launch");
 }
 

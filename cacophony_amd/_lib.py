@@ -68,6 +68,7 @@ _SIGNATURES = {
     "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "caco_op_attention": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_set_attention64": (C.c_int, [_i32]),
     "caco_op_attention_qkv": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "caco_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 }

@@ -957,6 +957,8 @@ int caco_op_layernorm(const float* x, const float* g, const float* b, int64_t ro
                       void* ob, void* stream) {
   return layernorm(x, g, b, rows, dim, eps, of, (bf16_t*)ob, (hipStream_t)stream);
 }
+int caco_set_attention64(int32_t on) { return set_attention64(on); }
+
 int caco_op_attention_qkv(const void* q, int32_t q_ld, int32_t seq_q, const void* kv, int32_t ld, int32_t k_off, int32_t v_off,
                           const float* mask, int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal,
                           void* out, void* stream) {

@@ -94,6 +94,9 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   }
 
   int ntiles = (S + KT - 1) / KT;
+#ifdef ATTN_ONETILE
+  ntiles = 1;
+#endif
   if (CAUSAL) {
     const int last_q = min(qb * QB + QB - 1, S - 1);
     ntiles = min(ntiles, last_q / KT + 1);
@@ -258,13 +261,20 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
         bf16x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
+#ifdef ATTN_NOSTORE
+        if (v[0] == (bf16_t)12345.f) *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
+#else
         *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
+#endif
       }
   }
 }
 
+#ifndef ATTN_OCC
+#define ATTN_OCC 3          // workgroups per CU the register budget is held to (164 VGPRs)
+#endif
 template <int HD, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, 3) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
+__global__ __launch_bounds__(NW * 64, ATTN_OCC) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
                                                                bf16_t* __restrict__ out, float scale_log2) {
@@ -272,6 +282,16 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_kernel(const bf16_t* __r
 }
 
 }  // namespace
+
+static int g_attn64 = -1;
+int attention64_enabled() {
+  if (g_attn64 < 0) g_attn64 = (getenv("CACO_ATTN64") && atoi(getenv("CACO_ATTN64"))) ? 1 : 0;
+  return g_attn64;
+}
+int set_attention64(int on) {
+  g_attn64 = on ? 1 : 0;
+  return g_attn64;
+}
 
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st) {
@@ -286,6 +306,14 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);
   CACO_REQUIRE(!causal || seq_q == seq, "attention: the causal mask needs seq_q == seq (%d vs %d)", seq_q, seq);
   CACO_REQUIRE(q_ld % 8 == 0, "attention: query row stride must be a multiple of 8 elements");
+  CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
+  CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
+  CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
+  {   // Opt-in experiment (CACO_ATTN64=1): the two-pass 64-rows-per-wave kernel of attention64.hip for non-causal shapes.
+      // Same results (same tests), measured 10 % SLOWER than this kernel at the encoder shape (460 vs 415 us) and 20 % at
+      // S = 1500: see the header of attention64.hip and DESIGN.md 4.2 for the cycle anatomy.
+    if (attention64_enabled() && !causal && seq_q >= 128) return attention64(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, out, st);
+  }
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");

@@ -689,7 +689,11 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
     // measured -4..-5 % on the out-proj / fc2 shapes, but +29 % on the bf16 QKV shape (N = 2304), where letting
     // every CU run ahead with 16 more stores in flight makes the HBM write bursts collide
     // (buffer stores of rows past M are dropped by the descriptor but still issue, so the count is exact)
+#ifdef W8_RELAX_BF16
+    stores_pending = (MODE != 0 || !p.xb_out == !p.stats_part);
+#else
     stores_pending = (EPI == EPI_F32) && (MODE != 0 || !p.xb_out == !p.stats_part);
+#endif
 #endif
 #endif
     c_li += slots;

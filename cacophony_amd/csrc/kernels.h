@@ -64,6 +64,12 @@ int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
                   int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st);
 
+int attention64_enabled();
+int set_attention64(int on);
+// attention64.hip: non-causal form with 64 query rows per wave, one wave per SIMD
+int attention64(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
+                int batch, int seq, int heads, int head_dim, bf16_t* out, hipStream_t st);
+
 // pool.hip: learned-query attention pooling over the encoder output rows themselves (projections folded out):
 // x bf16 [B, S, H], wq fp32 [heads, H] -> out fp32 [B, heads, H]
 int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,

@@ -186,6 +186,10 @@ int caco_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int caco_op_attention(const void* qkv_dev, int32_t ld, int32_t k_off, int32_t v_off, const float* key_mask_dev,
                       int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out_dev,
                       void* stream);
+/* Tuning knob (experiment): 1 routes non-causal attention with >= 128 query rows to the two-pass 64-rows-per-wave
+ * kernel (csrc/attention64.hip; env CACO_ATTN64=1 selects it at first use).  Default 0: measured slower.  Returns the
+ * setting in effect. */
+int caco_set_attention64(int32_t on);
 /* The same kernel with separate operands (cross-attention, RobertaSelfAttention with key_value_states,
  * roberta.py:67-104): queries q_dev bf16 [B*seq_q, q_ld] (head h at column h*head_dim), keys / values kv_dev bf16
  * [B*seq, ld] at columns k_off / v_off, key_mask_dev fp32 [B, seq] or NULL -> out_dev bf16 [B*seq_q, heads*head_dim].

@@ -150,10 +150,18 @@ def _attention_ref(qk, v, key_mask, heads, hd, causal):
     return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, S, H)
 
 
+@pytest.fixture(params=[0, 1], ids=["attn32", "attn64_two_pass"])
+def attn_kernel(request, lib):
+    """both non-causal kernels: the default and the opt-in two-pass 64-rows-per-wave form (csrc/attention64.hip)"""
+    assert lib.caco_set_attention64(request.param) == request.param
+    yield request.param
+    lib.caco_set_attention64(0)
+
+
 @pytest.mark.parametrize("B,S,heads,hd,causal,valid", [
     (2, 500, 8, 96, 0, [496, 144]), (3, 32, 12, 64, 1, [32, 12, 1]), (1, 1500, 8, 96, 0, [1496]),
     (2, 100, 12, 64, 1, [100, 37]), (2, 64, 8, 96, 0, [64, 64]), (1, 130, 8, 96, 1, [129])])
-def test_attention(lib, B, S, heads, hd, causal, valid):
+def test_attention(lib, B, S, heads, hd, causal, valid, attn_kernel):
     H = heads * hd
     qk = _rand((B, S, 2 * H), 20, 1.5).bfloat16()
     v = _rand((B, S, H), 21).bfloat16()
@@ -178,7 +186,7 @@ def test_attention(lib, B, S, heads, hd, causal, valid):
 @pytest.mark.parametrize("B,Sq,S,heads,hd,valid", [
     (2, 32, 500, 12, 64, [496, 144]), (3, 1, 500, 12, 64, [500, 7, 1]), (2, 20, 70, 12, 64, [50, 70]),
     (1, 200, 33, 8, 96, [33]), (2, 129, 64, 12, 64, [64, 5])])
-def test_cross_attention(lib, B, Sq, S, heads, hd, valid):
+def test_cross_attention(lib, B, Sq, S, heads, hd, valid, attn_kernel):
     """queries and keys/values from different buffers and lengths (caption decoder cross-attention, roberta.py:67-104)."""
     H = heads * hd
     q = _rand((B, Sq, H), 40, 1.5).bfloat16()

@@ -252,7 +252,8 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   if (!wave_active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_row < Sq) {
+#ifdef ATTN_DIRECT_STORE
+  if (q_row < Sq) {        // 8-byte pieces at a row stride: 32 lines per store instruction (measured 57 of 405 us)
     bf16_t* op = out + (qrow_base + q_row) * H + h * HD + 4 * hf;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -261,13 +262,39 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
         bf16x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
-#ifdef ATTN_NOSTORE
-        if (v[0] == (bf16_t)12345.f) *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
-#else
         *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
-#endif
       }
   }
+#else
+  // The output leaves as whole rows: this wave's 32 x HD block is staged in LDS (the K / V ring is dead: the loop's
+  // last barrier is behind every wave; the region is wave-private) and stored 16 bytes per lane, consecutive lanes on
+  // consecutive chunks of a row.  Lane (l31, hf) holds query row l31, columns dt*32 + g*8 + 4*hf .. +3; the staging
+  // pitch RP + 16 keeps the 8-byte writes conflict-free.
+  constexpr int OPITCH = RP + 16;
+  static_assert(NW * 32 * OPITCH <= 2 * BUF, "output staging must fit in the K / V ring");
+  char* stage = smem + wave * (32 * OPITCH);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
+      *reinterpret_cast<bf16x4*>(stage + l31 * OPITCH + (dt * 32 + g * 8 + 4 * hf) * 2) = v;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int rows_valid = min(32, Sq - q0);
+  const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
+      out + (qrow_base + q0) * H + h * HD, 0, (rows_valid - 1) * H * 2 + RP, 0x00020000);    // rows past Sq fall outside
+#pragma unroll
+  for (int it = 0; it < KCH / 2; ++it) {                   // 32 rows x KCH chunks of 16 B = KCH / 2 wave instructions
+    const int L = it * 64 + lane;
+    const int r = L / KCH, c = L % KCH;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * OPITCH + c * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, 0);
+  }
+#endif
 }
 
 #ifndef ATTN_OCC

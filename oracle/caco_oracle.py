@@ -571,6 +571,26 @@ class CacoOracle:
         return o.to_numpy(roberta_decoder(o, self.P, self.decoder_cfg, o.f32(th), o.i64(text_mask),
                                           o.f32(audio_hidden_state), o.f32(audio_mask)))
 
+    def greedy_decode(self, audio_hidden_state, audio_mask, max_decode_length: int, bos_id: int = 0, eos_id: int = 2,
+                      pad_id: int = 1):
+        """The decoding loop the reference intends (eval_caco_torch.py:412-461 with the call of caco.py:212-240; per-row
+        stop as in the JAX loop src/caco/caco.py:180-199), arg-max instead of sampling.  Returns (ids [B, L], margins
+        [B, L-1] = top-1 minus top-2 logit of every emitted token, for tests that compare against a bf16 path)."""
+        b = np.asarray(audio_hidden_state).shape[0]
+        gen = np.full((b, 1), bos_id, dtype=np.int64)
+        alive = np.ones(b, dtype=bool)
+        margins = []
+        for _ in range(max_decode_length):
+            lg = self.get_decoder_logits(audio_hidden_state, audio_mask, gen, np.ones_like(gen))[:, -1]
+            top2 = np.sort(lg, axis=-1)[:, -2:]
+            margins.append(top2[:, 1] - top2[:, 0])
+            nxt = np.where(alive, lg.argmax(-1), pad_id)
+            gen = np.concatenate([gen, nxt[:, None]], axis=1)
+            alive &= nxt != eos_id
+            if not alive.any():
+                break
+        return gen, np.stack(margins, axis=1)
+
     # convenience wrappers named in BASELINE.json north_star (SURVEY.md section 8b)
     def encode_audio(self, wav, max_patches: int = 500):
         b = prepare_audio_batch(wav, max_patches, backend=self.ops.name)

@@ -115,3 +115,41 @@ def test_decoder_error_behaviour(dec_model, tiny_state):
     # a model built WITH the decoder refuses a state dict that lacks decoder_module.*
     with pytest.raises((ValueError, RuntimeError), match="decoder_module"):
         CACO(a, t, cc, decoder_config=d, device="cuda:0").load_state_dict(tiny_state)
+
+
+@pytest.mark.gpu
+def test_greedy_caption_loop_vs_oracle(dec_model, dec_state):
+    """decode_caption's loop (eval_caco_torch.py:412-461) with arg-max: token for token against the oracle's fp32 loop as
+    long as the oracle's own top-1 / top-2 margin exceeds what bf16 operands can flip."""
+    from cacophony_amd import captioning, frontend
+    a, t, cc, d = _configs()
+    o = O.CacoOracle(dec_state, a, t, cc, backend="torch", decoder_cfg=d)
+    wav = synth.make_waveforms(2, start=40)
+    ab = frontend.mel_patches_device(torch.from_numpy(wav).cuda(), 500, torch.float32)
+    ids = captioning.decode_caption_ids(dec_model, ab, max_decode_length=8, greedy=True, bos_id=0, eos_id=2, pad_id=1).cpu().numpy()
+    batch = O.prepare_audio_batch(wav, 500, backend="torch")
+    _, ah = o.get_audio_embedding(batch["audio_patches"], batch["audio_time_inds"], batch["audio_freq_inds"], batch["audio_mask"])
+    ref, margin = o.greedy_decode(ah, batch["audio_mask"], 8)
+    assert ids.shape[0] == 2 and ids.shape[1] <= 9 and (ids[:, 0] == 0).all()
+    compared = 0
+    for b in range(2):
+        for p in range(1, min(ids.shape[1], ref.shape[1])):
+            if margin[b, p - 1] < 0.02:          # a near-tie: later tokens are conditioned on different prefixes
+                break
+            assert ids[b, p] == ref[b, p], f"clip {b} position {p}: {ids[b]} vs {ref[b]}"
+            compared += 1
+    assert compared >= 4
+    # sampling path runs and respects the length bound and the per-row stop
+    g = torch.Generator(device="cuda").manual_seed(0)
+    sm = captioning.decode_caption_ids(dec_model, ab, max_decode_length=5, temperature=0.1, generator=g)
+    assert sm.shape[0] == 2 and 2 <= sm.shape[1] <= 6 and int(sm.max()) < t.vocab_size
+
+    class Tok:                                    # the three attributes + batch_decode decode_caption uses
+        bos_token_id, eos_token_id, pad_token_id = 0, 2, 1
+        def batch_decode(self, x, skip_special_tokens=True):
+            return [" ".join(str(int(v)) for v in row if int(v) > 2) for row in x]
+    text = captioning.decode_caption(dec_model, Tok(), ab, max_decode_length=4, greedy=True)
+    assert text == " ".join(str(int(v)) for v in ids[0, 1:5] if int(v) > 2)
+    from cacophony_amd.model import CACO
+    with pytest.raises(ValueError, match="decoder module"):
+        captioning.decode_caption_ids(CACO(a, t, cc, device="cuda:0").load_state_dict(synth.make_caco_state(a, t, cc)), ab)

@@ -411,6 +411,7 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
 // forms carry no per-element branches or phi copies (the generic form measured 400 v_mov + 70 branches per tile):
 //   0 generic: bias / residual / LayerNorm-fold consumer / producer outputs all tested at run time
 //   1 bias only        2 bias + residual (EPI_F32)
+//   3 bias + LayerNorm-fold consumer (EPI_BF16)        4 bias + residual + fold producer (EPI_F32: bf16 copy + row sums)
 // Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
 // fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
 // (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
@@ -440,7 +441,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
     const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
     const int voff = rrow * rowb + c8 * 16;
-    const bool fold = MODE ? false : p.fold_mr != nullptr;          // LayerNorm folded into this GEMM (kernels.h)
+    const bool fold = MODE ? MODE == 3 : p.fold_mr != nullptr;      // LayerNorm folded into this GEMM (kernels.h)
     const float* bias_l = has_bias ? p.bias + nw + lh * 4 : nullptr;
     const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
 #pragma unroll
@@ -465,7 +466,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = MODE ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
+            const float x = MODE == 1 ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
             o[r] = (bf16_t)w4_epi_act<ACT>(x);
           }
           *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
@@ -484,14 +485,16 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
     const int rowb = p.ldc * 4;
     const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
-    const bool has_resid = MODE ? MODE == 2 : p.resid != nullptr;
-    const bool produce_xb = MODE ? false : p.xb_out != nullptr;
-    const bool produce_st = MODE ? false : p.stats_part != nullptr;
+    const bool has_resid = MODE ? (MODE == 2 || MODE == 4) : p.resid != nullptr;
+    const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
+    const bool produce_st = MODE ? MODE == 4 : p.stats_part != nullptr;
     const __amdgpu_buffer_rsrc_t out_r =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
     const int voff = rrow * rowb + c8 * 16;
+    const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
+        produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
     u32x4 res[2][4];
     float st1[4][4], st2[4][4];
     auto fetch = [&](int s, u32x4 (&dst)[4]) {
@@ -518,14 +521,12 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
         if (has_resid) v += __builtin_bit_cast(f32x4, res[s & 1][tt]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
-        if (produce_xb) {
-          const int64_t m = mw + i * 32 + row;
-          if (m < p.M) {
-            bf16x4 b;
+        if (produce_xb) {         // bf16 copy of the new rows: the next (LayerNorm-folded) GEMM's A operand, default cache policy
+          bf16x4 b;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(p.xb_out + m * p.ldc + nw + j * 32 + c8 * 4) = b;
-          }
+          for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff >> 1), ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
         }
         if (produce_st) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
           const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
@@ -766,6 +767,13 @@ static int gemm_bf16_w_t(const GemmArgs& p, int epi, int act, hipStream_t st) {
       if (p.resid) return launch_w4<EPI_F32, ACT_NONE, 8, 2>(p, st);
       return launch_w4<EPI_F32, ACT_NONE, 8, 1>(p, st);
     }
+    // LayerNorm-folded stack (api.hip run_audio_layers): consumer = bias + fold, producer = bias + residual + bf16 copy + sums
+    if (!generic && p.bias && p.fold_mr && !p.resid && !p.xb_out && !p.stats_part && epi == EPI_BF16) {
+      if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, 8, 3>(p, st);
+      if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, 8, 3>(p, st);
+    }
+    if (!generic && p.bias && p.resid && p.xb_out && p.stats_part && !p.fold_mr && epi == EPI_F32 && act == ACT_NONE)
+      return launch_w4<EPI_F32, ACT_NONE, 8, 4>(p, st);
   }
   if (epi == EPI_BF16) {
     if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, NWV>(p, st);

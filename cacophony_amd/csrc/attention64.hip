@@ -1,24 +1,31 @@
-// Fused attention, 64 query rows per wave, TWO-PASS softmax: the non-causal (audio / cross-attention) form of
-// attention.hip, built around what the counters and ablations of that kernel showed:
-//   * co-resident waves do not overlap each other's MFMA and softmax phases (3, 2, 1 workgroups per CU: same time,
-//     -16 % at 1), and every VALU instruction of the softmax costs its full issue time next to the MFMAs: the kernel
-//     runs at the SUM of its matrix and vector work;
-//   * the online-softmax rescale (VALU work on the O accumulators inside the loop) forces O into the architectural
-//     VGPRs, which at 64 rows per wave no longer fit: the compiler then shuttles O between the two register files
-//     (380-430 copy instructions per tile, measured).
-// So: every wave owns TWO 32-row query blocks (A, B), ONE wave per SIMD, and the softmax is exact two-pass:
-//   pass 1  S^T = K Q^T per tile, running row maximum only (12 MFMAs + 17 VALU per block and tile);
-//   pass 2  S^T again (bit-identical), P = exp2((S - max) * scale) with the FINAL maximum, O^T += V^T P^T.
-// No running maximum, no rescale, no branch in the loop body: O lives in accumulation registers untouched by the
-// VALU, block B's MFMAs sit next to block A's exponentials and vice versa (sched_group_barrier pins the interleave),
-// P <= 1 always (better conditioned than the online form).  Price: the QK^T MFMAs run twice (+50 % matrix work, K
-// tiles fetched twice from L2) - the kernel becomes matrix-bound instead of issue-bound.
+// Fused attention, 64 query rows per wave: the opt-in experimental form of attention.hip for non-causal shapes
+// (caco_set_attention64(1) / CACO_ATTN64=1), built around what the counters and ablations of that kernel showed
+// (DESIGN.md 4.2):
+//   * co-resident waves barely overlap each other's MFMA and softmax phases (3, 2, 1 workgroups per CU: same time, -16 %
+//     at 1): the kernel runs at the SUM of its matrix and vector work, so the overlap has to be arranged INSIDE a wave;
+//   * a lone wave issues one vector instruction per ~5 ns whatever its type; two waves per SIMD are needed for the VALU
+//     rate.
+// So: every wave owns TWO independent 32-row query blocks (A, B); 8 waves = 2 per SIMD = all 512 query rows of one
+// (clip, head) per workgroup, every K / V tile fetched once; block B's MFMAs are interleaved with block A's softmax
+// and vice versa (sched_group_barrier pins MFMA : fragment-read : VALU patterns, fragments one step ahead); Q is staged
+// in LDS once (DMA, swizzled like K) and its fragments re-read per tile; the output leaves through an LDS staging tile as
+// whole rows.  Built with -mllvm -amdgpu-mfma-vgpr-form (cacophony_amd/build.py): with the default accumulation-register
+// form the compiler shuttles O (online rescale) or S (softmax input) between the two register files, 380-430 copy
+// instructions per tile.
+//
+// Two softmax forms:
+//   default            single pass, online softmax (running maximum, conditional O rescale between two regions);
+//   -DATTN64_TWO_PASS  exact two-pass: pass 1 row maxima only, pass 2 exp2 with the FINAL maximum - no rescale, no
+//                      branch, P <= 1 always; +50 % Q.K^T MFMAs.
+// Measured at the encoder shape (B 256, S 500, 8 x 96): default kernel (attention.hip) 385-415 us, this one 394 us
+// single-pass / 460 us two-pass (box to box +-5 %): a draw, which is why it is not the default.  Per-region cycle
+// stamps (-DATTN_TIMING, tools/attn64_timing.py) show where it goes: the Q.K^T regions take 2-3 x their MFMA time (18
+// LDS fragment reads per 12 MFMAs with all 8 waves in the same phase), the second wave of each SIMD runs up to 1.7 x
+// slower than the first in the mixed regions, and the first then waits ~15 k of its 78 k cycles at the tile barriers.
 //
 // Everything else is attention.hip's design: swapped products so that softmax is lane-local, the key permutation
 // that makes P an MFMA operand without leaving registers, K / V tiles of 64 keys by 16-byte LDS-DMA into unpadded rows
-// (K chunk-swizzled on the source address), V through ds_read_b64_tr_b16, fp32 statistics.  New here: Q is staged in
-// LDS once (DMA, swizzled like K) and its fragments re-read per tile; the output leaves through an LDS staging tile
-// as whole 192-byte rows (16-byte stores) instead of 8-byte pieces at a row stride.
+// (K chunk-swizzled on the source address), V through ds_read_b64_tr_b16, fp32 statistics.
 #include "common.h"
 #include "kernels.h"
 
@@ -242,6 +249,83 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ qp_,
 #else
 #define A64_STAMP(k)
 #endif
+#ifndef ATTN64_TWO_PASS
+  // ---- single pass, online softmax (default) ----------------------------------------------------------------------------
+  // One block's step: tile maximum, new running maximum, P = exp2((S - max) * scale), row sum; branch-free (it shares a
+  // scheduling region with the other block's MFMAs).  Returns the factor the block's O must be multiplied by before its
+  // next P.V and whether any row's maximum moved (the caller rescales only then, between two regions).
+  auto softmax_step = [&](const f32x16 (&s)[2], float& m_run, float& l_acc, bf16x8 (&pf)[4], float& alpha, bool& moved) {
+    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    tile_max(s, m4);
+    float m_tile = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    exp_step(s, -m_use * scale_log2, ps2, pf);
+    moved = __ballot(m_new > m_run) != 0ull;
+    alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2);     // m_run = -inf -> 0; unchanged maximum -> 1
+    l_acc = l_acc * alpha + ((ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]));
+    m_run = m_new;
+  };
+  auto rescale = [&](int sb, float alpha) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[sb][dt][r] *= alpha;
+  };
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[sb][dt][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x16 sA[2], sB[2];
+  bf16x8 pA[4], pB[4];
+  float alphaA, alphaB;
+  bool movedA, movedB;
+  issue_tile(0, 0, true);
+  finish_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile 0 and this wave's Q block
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue_tile(t + 1, buf ^ 1, true);
+    const bool padded = tile_padded(buf);
+    // R1: QK_A
+    qk(0, tile_k(buf), sA);
+    A64_SGB_QK(0)
+    __builtin_amdgcn_sched_barrier(0);
+    A64_STAMP(3)
+    if (padded) add_mask(tile_bias(buf), sA);
+    // R2: QK_B || softmax_A
+    qk(1, tile_k(buf), sB);
+    softmax_step(sA, m_run[0], l_run[0], pA, alphaA, movedA);
+    A64_SGB_QK(8)
+    // (use the products here: otherwise the compiler sinks the exponentials into the next region, away from these MFMAs)
+    asm volatile("" ::"v"(pA[0]), "v"(pA[1]), "v"(pA[2]), "v"(pA[3]), "v"(l_run[0]), "v"(alphaA));
+    A64_STAMP(4)
+    if (movedA) rescale(0, alphaA);
+    if (padded) add_mask(tile_bias(buf), sB);
+    // R3: PV_A || softmax_B
+    pv(0, tile_v(buf), pA, false);
+    softmax_step(sB, m_run[1], l_run[1], pB, alphaB, movedB);
+    A64_SGB_PV(8)
+    asm volatile("" ::"v"(pB[0]), "v"(pB[1]), "v"(pB[2]), "v"(pB[3]), "v"(l_run[1]), "v"(alphaB));
+    A64_STAMP(5)
+    if (movedB) rescale(1, alphaB);
+    // R4: PV_B
+    pv(1, tile_v(buf), pB, false);
+    A64_SGB_PV(0)
+    A64_STAMP(6)
+    if (t + 1 < ntiles) finish_tile(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of tile t+1 have landed
+    A64_STAMP(7)
+    __syncthreads();
+    A64_STAMP(8)
+  }
+#else
   // ---- pass 1: exact row maxima ----------------------------------------------------------------------------------------
   float mA4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, mB4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   f32x16 sA[2], sB[2];
@@ -322,12 +406,13 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ qp_,
     __syncthreads();
     A64_STAMP(8)
   }
-#undef A64_SGB_QK
-#undef A64_SGB_PV
   float l_run[2];
   l_run[0] = (lA[0][0] + lA[0][1]) + (lA[1][0] + lA[1][1]);
   l_run[1] = (lB[0][0] + lB[0][1]) + (lB[1][0] + lB[1][1]);
+#endif
 
+#undef A64_SGB_QK
+#undef A64_SGB_PV
   // Epilogue: normalise, stage this wave's 64 x HD block in LDS (the K / V ring is dead: the loop's last barrier is
   // behind every wave), write whole rows.  Lane (l31, hf) holds query row l31, columns dt*32 + g*8 + 4*hf .. +3.
   char* stage = smem + wave * (64 * OP);

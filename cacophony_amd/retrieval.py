@@ -113,3 +113,23 @@ def audio_retrieval_scores(audio_emb: Tensor, text_emb: Tensor, k: int = 10, sim
     at_idx, _ = topk(logits_ar, k, dim=0)       # argsort(-logits_ar.T)
     ta_idx, _ = topk(logits_ar, k, dim=1)       # argsort(-logits_ar)
     return logits_ar, at_idx, ta_idx
+
+
+def zs_classification_scores(audio_emb: Tensor, class_text_emb: Tensor, target_idx, logit_scale: float = 0.0,
+                             ks: Sequence[int] = (1,)) -> Dict[str, float]:
+    """Zero-shot classification scoring, the arithmetic of `zs_classification` (src/eval/eval_caco_torch.py:326-340) for
+    a whole set of clips at once: logits = exp(logit_scale) * A @ T_classes^T, a clip counts as correct at k when its
+    target class is among the first k of argsort(-logits).  audio_emb [N, D], class_text_emb [C, D] (both as returned
+    with normalize=True), target_idx int [N].  The similarity and the top-k run on the device (caco_similarity,
+    caco_topk); only [N, max(ks)] indices come back.  Returns {"1": acc@1, ...} keyed like the reference's total_correct."""
+    from .model import similarity
+    kmax = int(max(ks))
+    if kmax < 1 or kmax > 64:
+        raise ValueError("zs_classification_scores: k must be in [1, 64]")
+    logits = similarity(audio_emb, class_text_emb, float(np.exp(logit_scale)))
+    idx, _ = topk(logits, kmax)
+    idx = idx.cpu().numpy()
+    tgt = np.asarray(target_idx.cpu() if torch.is_tensor(target_idx) else target_idx).astype(np.int64).reshape(-1)
+    if tgt.shape[0] != idx.shape[0]:
+        raise ValueError(f"zs_classification_scores: {tgt.shape[0]} targets for {idx.shape[0]} clips")
+    return {str(int(k)): float((idx[:, :int(k)] == tgt[:, None]).any(axis=1).mean()) for k in ks}

@@ -700,3 +700,11 @@ def hear_event_embeddings(hidden: np.ndarray, audio_max_len: float = 10.0, group
     ev = hidden[:, :n * group].reshape(b, n, group, h).astype(np.float64).mean(axis=2).astype(np.float32)
     ts = np.linspace(0, audio_max_len * 1000, n)
     return ev, ts
+
+
+def zs_topk_accuracy(audio_emb: np.ndarray, class_text_emb: np.ndarray, target_idx, logit_scale: float = 0.0, ks=(1,)):
+    """src/eval/eval_caco_torch.py:326-340 for all clips: exp(logit_scale) * A @ T^T, argsort(-logits), target in first k."""
+    logits = np.float32(math.exp(logit_scale)) * (np.asarray(audio_emb, np.float32) @ np.asarray(class_text_emb, np.float32).T)
+    order = np.argsort(-logits, axis=-1, kind="stable")
+    tgt = np.asarray(target_idx).reshape(-1)
+    return {str(int(k)): float((order[:, :int(k)] == tgt[:, None]).any(axis=1).mean()) for k in ks}

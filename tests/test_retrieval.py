@@ -109,3 +109,26 @@ def test_audio_retrieval_scores_end_to_end(scenario):
         assert abs(np.mean(m_ta[n]) - np.mean(g[f"ta_{n}"])) < 0.03
     with pytest.raises(ValueError):
         retrieval.topk(logits.double(), 10)
+
+
+def test_oracle_zero_shot_accuracy_known_answers():
+    # 4 classes on the axes, clips near their class axis except clip 2, which sits nearer class 3 (second choice: class 2)
+    T = np.eye(4, dtype=np.float32)
+    A = np.array([[1, .1, 0, 0], [.1, 1, 0, 0], [0, 0, .6, .8], [0, 0, .1, 1]], dtype=np.float32)
+    acc = O.zs_topk_accuracy(A, T, [0, 1, 2, 3], logit_scale=2.0, ks=(1, 2))
+    assert acc == {"1": 0.75, "2": 1.0}
+
+
+@pytest.mark.gpu
+def test_zero_shot_scores_device_vs_oracle():
+    rng = np.random.RandomState(3)
+    T = rng.randn(37, 768).astype(np.float32); T /= np.linalg.norm(T, axis=1, keepdims=True)
+    tgt = rng.randint(0, 37, size=300)
+    A = (0.35 * T[tgt] + rng.randn(300, 768).astype(np.float32) / np.sqrt(768)).astype(np.float32)
+    A /= np.linalg.norm(A, axis=1, keepdims=True)
+    ref = O.zs_topk_accuracy(A, T, tgt, logit_scale=2.6592, ks=(1, 5))
+    got = retrieval.zs_classification_scores(torch.from_numpy(A).cuda(), torch.from_numpy(T).cuda(), tgt, 2.6592, ks=(1, 5))
+    assert 0.2 < ref["1"] < 0.98 and ref["5"] >= ref["1"]          # informative
+    assert abs(got["1"] - ref["1"]) <= 1 / 300 + 1e-9 and abs(got["5"] - ref["5"]) <= 1 / 300 + 1e-9   # fp32 MFMA vs BLAS: at most one near-tie
+    with pytest.raises(ValueError):
+        retrieval.zs_classification_scores(torch.from_numpy(A).cuda(), torch.from_numpy(T).cuda(), tgt[:5])

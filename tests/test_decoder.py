@@ -153,3 +153,30 @@ def test_greedy_caption_loop_vs_oracle(dec_model, dec_state):
     from cacophony_amd.model import CACO
     with pytest.raises(ValueError, match="decoder module"):
         captioning.decode_caption_ids(CACO(a, t, cc, device="cuda:0").load_state_dict(synth.make_caco_state(a, t, cc)), ab)
+
+
+@pytest.mark.gpu
+def test_decoder_vocab_not_multiple_of_tile():
+    """The real vocabulary (50265) is not a multiple of the GEMM tile: decoder_proj runs on rows padded to x256 and the
+    logits are copied out with a row stride.  Exercised here with vocab 1000 against the oracle (itself pinned to the
+    reference by decoder_tiny.npz at vocab 1024)."""
+    from cacophony_amd.model import CACO
+    a, t, cc = C.tiny_configs(1)
+    t = replace(t, vocab_size=1000)
+    d = replace(t, num_hidden_layers=1)
+    state = synth.make_caco_state(a, t, cc, seed=3, decoder_cfg=d)
+    model = CACO(a, t, cc, decoder_config=d, device="cuda:0").load_state_dict(state)
+    o = O.CacoOracle(state, a, t, cc, backend="torch", decoder_cfg=d)
+    rng = np.random.RandomState(11)
+    th = rng.randn(3, 9, t.hidden_size).astype(np.float32)
+    ah = rng.randn(3, 40, t.hidden_size).astype(np.float32)
+    tm = np.ones((3, 9), dtype=np.int64); tm[2, 5:] = 0
+    am = np.ones((3, 40), dtype=np.float32); am[1, 33:] = 0
+    got = model.decoder_module(th, tm, ah, am).cpu().numpy()
+    ops = o.ops
+    ref = ops.to_numpy(O.roberta_decoder(ops, o.P, d, ops.f32(th), ops.i64(tm), ops.f32(ah), ops.f32(am)))
+    assert got.shape == ref.shape == (3, 9, 1000)
+    keep = tm.astype(bool)
+    assert rel_l2(got[keep], ref[keep]) < LOGIT_TOL
+    assert cosine_rows(got[keep], ref[keep]).min() > COS_TOL
+    assert np.isfinite(got).all()

@@ -180,3 +180,26 @@ def test_decoder_vocab_not_multiple_of_tile():
     assert rel_l2(got[keep], ref[keep]) < LOGIT_TOL
     assert cosine_rows(got[keep], ref[keep]).min() > COS_TOL
     assert np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+def test_decoder_full_vocabulary():
+    """RoBERTa's real vocabulary (50265 -> 50432 padded rows, 197 column tiles): logits against the oracle on a 1+1-layer
+    model, and the arg-max over the 50265 real columns never lands in the padding."""
+    from cacophony_amd.model import CACO
+    a, t, cc = C.tiny_configs(1)
+    t = replace(t, vocab_size=50265)
+    d = replace(t, num_hidden_layers=1)
+    state = synth.make_caco_state(a, t, cc, seed=4, decoder_cfg=d)
+    model = CACO(a, t, cc, decoder_config=d, device="cuda:0").load_state_dict(state)
+    o = O.CacoOracle(state, a, t, cc, backend="torch", decoder_cfg=d)
+    rng = np.random.RandomState(12)
+    ids, tmask = synth.make_captions(2, 8, t.vocab_size, start=70)
+    ah = rng.randn(2, 24, t.hidden_size).astype(np.float32)
+    am = np.ones((2, 24), dtype=np.float32)
+    got = model.get_decoder_logits(ah, am, ids, tmask).cpu().numpy()
+    ref = o.get_decoder_logits(ah, am, ids, tmask)
+    assert got.shape == ref.shape == (2, 8, 50265)
+    keep = tmask.astype(bool)
+    assert rel_l2(got[keep], ref[keep]) < LOGIT_TOL
+    assert cosine_rows(got[keep], ref[keep]).min() > COS_TOL

@@ -429,9 +429,19 @@ struct Arena {
   T* at(size_t o) const { return reinterpret_cast<T*>(w->p + o); }
 };
 
-int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st) {
-  GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, L.out};
+int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st, int ldc = 0) {
+  GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, ldc ? ldc : L.out};
   return gemm_bf16(g, EPI_BF16, act, st);
+}
+// Row stride (elements) of the fused Q | K | V buffer: rows padded to a multiple of 512 elements (3H = 2304 -> 2560).
+// In ISOLATION (the same GEMM launched back to back, tools/gemm_ldc_bench.py) the 4608-byte pitch of 3H = 2304 is
+// pathological for the 128 000-row QKV GEMM's stores: 496 us at 2304, 425 at 2432, 401 at 2560, 398 at 3072, while every
+// other pitch on the path (1536, 3072, 6144 bytes) is insensitive.  Inside the pipeline the GEMM itself does not care
+// (5.04 ms per step either way, A/B on one box); the attention kernel reading the buffer gains 1.5 %.  CACO_QKV_PAD=0
+// turns it off.
+inline int qkv_ld(int H) {
+  static const int pad = getenv("CACO_QKV_PAD") ? atoi(getenv("CACO_QKV_PAD")) : 1;
+  return pad ? (3 * H + 511) / 512 * 512 : 3 * H;
 }
 int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st) {
   GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out};
@@ -450,7 +460,7 @@ struct AudioWs {
     h = A.reserve((size_t)M * H * 2);
     part = A.reserve((size_t)M * (H / 64) * 8);     // LayerNorm folding: per-row partial (sum, sumsq) per 64 columns
     mr = A.reserve((size_t)M * 8);                  // per-row (mean, rstd)
-    qkv = A.reserve((size_t)M * 3 * H * 2);
+    qkv = A.reserve((size_t)M * qkv_ld(H) * 2);
     o = A.reserve((size_t)M * H * 2);
     a = A.reserve((size_t)M * I * 2);
   }
@@ -462,8 +472,8 @@ struct AudioWs {
 // epilogue runs with the matrix pipe idle.  Kept as an option (and tested) until the epilogue overlaps the K-loop.
 static int g_ln_fold = getenv("CACO_LN_FOLD") ? atoi(getenv("CACO_LN_FOLD")) : 0;
 
-int linear_fold(const LinFold& L, const bf16_t* xb, const float* mr, int64_t M, int act, bf16_t* out, hipStream_t st) {
-  GemmArgs g{xb, L.lin.w, L.lin.b, nullptr, out, M, L.lin.out, L.lin.in, L.lin.out};
+int linear_fold(const LinFold& L, const bf16_t* xb, const float* mr, int64_t M, int act, bf16_t* out, hipStream_t st, int ldc = 0) {
+  GemmArgs g{xb, L.lin.w, L.lin.b, nullptr, out, M, L.lin.out, L.lin.in, ldc ? ldc : L.lin.out};
   g.fold_mr = mr;
   g.fold_c1 = L.c1;
   return gemm_bf16(g, EPI_BF16, act, st);
@@ -498,8 +508,8 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
     bf16_t* xb = h;                 // the bf16 operand buffer holds the RAW rows in this form
     CACO_STAGE("audio.ln", row_stats_bf16(x, M, H, eps, xb, mr, st));       // once per stack, at its entry
     for (const AudioLayer& L : layers) {
-      CACO_STAGE("audio.gemm_qkv", linear_fold(L.qkv_f, xb, mr, M, ACT_NONE, qkv, st));
-      CACO_STAGE("audio.attention", attention(qkv, 3 * H, H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
+      CACO_STAGE("audio.gemm_qkv", linear_fold(L.qkv_f, xb, mr, M, ACT_NONE, qkv, st, qkv_ld(H)));
+      CACO_STAGE("audio.attention", attention(qkv, qkv_ld(H), H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
       CACO_STAGE("audio.gemm_out", linear_resid_stats(L.o, o, M, x, xb, part, st));
       CACO_STAGE("audio.ln_stats", ln_stats_finalize(part, H / 64, M, H, eps, mr, st));
       CACO_STAGE("audio.gemm_fc1", linear_fold(L.fc1_f, xb, mr, M, ACT_SILU, a, st));
@@ -510,8 +520,8 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   }
   for (const AudioLayer& L : layers) {
     CACO_STAGE("audio.ln", layernorm(x, L.ln1.g, L.ln1.b, M, H, eps, nullptr, h, st));
-    CACO_STAGE("audio.gemm_qkv", linear_bf16(L.qkv, h, M, ACT_NONE, qkv, st));
-    CACO_STAGE("audio.attention", attention(qkv, 3 * H, H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
+    CACO_STAGE("audio.gemm_qkv", linear_bf16(L.qkv, h, M, ACT_NONE, qkv, st, qkv_ld(H)));
+    CACO_STAGE("audio.attention", attention(qkv, qkv_ld(H), H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
     CACO_STAGE("audio.gemm_out", linear_f32(L.o, o, M, x, x, st));
     CACO_STAGE("audio.ln", layernorm(x, L.ln2.g, L.ln2.b, M, H, eps, nullptr, h, st));
     CACO_STAGE("audio.gemm_fc1", linear_bf16(L.fc1, h, M, ACT_SILU, a, st));
@@ -755,7 +765,7 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   const int64_t M = (int64_t)batch * seq;
   Arena A(m, WS_TEXT, st);
   const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
-  const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2);
+  const size_t o_qkv = A.reserve((size_t)M * qkv_ld(H) * 2);
   const size_t o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
   const size_t o_mask = A.reserve((size_t)M * 4), o_pv = A.reserve((size_t)batch * H * 4);
   const size_t o_pool = A.reserve((size_t)batch * H * 4), o_emb = A.reserve((size_t)batch * c.projection_size * 4);
@@ -775,8 +785,8 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   const int nl = (int)m->tlayers.size();
   for (int n = 0; n < nl; ++n) {
     const TextLayer& L = m->tlayers[n];
-    CACO_STAGE("text.gemm_qkv", linear_bf16(L.qkv, xb, M, ACT_NONE, qkv, st));
-    CACO_STAGE("text.attention", attention(qkv, 3 * H, H, 2 * H, fmask, batch, seq, c.text_heads, H / c.text_heads, 1, o, st));
+    CACO_STAGE("text.gemm_qkv", linear_bf16(L.qkv, xb, M, ACT_NONE, qkv, st, qkv_ld(H)));
+    CACO_STAGE("text.attention", attention(qkv, qkv_ld(H), H, 2 * H, fmask, batch, seq, c.text_heads, H / c.text_heads, 1, o, st));
     CACO_STAGE("text.gemm_out", linear_f32(L.attn_out, o, M, x, y, st));
     CACO_STAGE("text.ln", layernorm(y, L.ln_attn.g, L.ln_attn.b, M, H, c.text_ln_eps, x, xb, st));
     CACO_STAGE("text.gemm_fc1", linear_bf16(L.inter, xb, M, ACT_GELU, a, st));
@@ -811,7 +821,7 @@ int caco_decoder_forward(caco_model* m, const float* text_hidden, const int64_t*
   const int64_t M = (int64_t)batch * seq_t, Ma = (int64_t)batch * seq_a;
   Arena A(m, WS_TEXT, st);
   const size_t o_x = A.reserve((size_t)M * H * 4), o_y = A.reserve((size_t)M * H * 4), o_xb = A.reserve((size_t)M * H * 2);
-  const size_t o_qkv = A.reserve((size_t)M * 3 * H * 2), o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
+  const size_t o_qkv = A.reserve((size_t)M * qkv_ld(H) * 2), o_o = A.reserve((size_t)M * H * 2), o_a = A.reserve((size_t)M * I * 2);
   const size_t o_mask = A.reserve((size_t)M * 4), o_ab = A.reserve((size_t)Ma * H * 2), o_kv = A.reserve((size_t)Ma * 2 * H * 2);
   const size_t o_lg = A.reserve((size_t)M * Vp * 4);
   CACO_TRY(A.commit(st));
@@ -831,8 +841,8 @@ int caco_decoder_forward(caco_model* m, const float* text_hidden, const int64_t*
   CACO_STAGE("decoder.cast", cast_f32_to_bf16(audio_hidden, ab, Ma * H, st));
   for (const DecLayer& L : m->dlayers) {
     // self-attention: causal AND caption-padding mask (roberta.py:347-356)
-    CACO_STAGE("decoder.gemm_qkv", linear_bf16(L.t.qkv, xb, M, ACT_NONE, qkv, st));
-    CACO_STAGE("decoder.attention", attention(qkv, 3 * H, H, 2 * H, fmask, batch, seq_t, heads, hd, 1, o, st));
+    CACO_STAGE("decoder.gemm_qkv", linear_bf16(L.t.qkv, xb, M, ACT_NONE, qkv, st, qkv_ld(H)));
+    CACO_STAGE("decoder.attention", attention(qkv, qkv_ld(H), H, 2 * H, fmask, batch, seq_t, heads, hd, 1, o, st));
     CACO_STAGE("decoder.gemm_out", linear_f32(L.t.attn_out, o, M, x, y, st));
     CACO_STAGE("decoder.ln", layernorm(y, L.t.ln_attn.g, L.t.ln_attn.b, M, H, c.text_ln_eps, x, xb, st));
     // cross-attention over the audio tokens: queries from the caption, keys / values from the audio hidden states,

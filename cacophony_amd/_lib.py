@@ -70,6 +70,9 @@ _SIGNATURES = {
     "caco_op_attention": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "caco_set_attention64": (C.c_int, [_i32]),
     "caco_op_attention_qkv": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "caco_decode_begin": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "caco_decode_step": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "caco_decode_end": (None, [_vp]),
     "caco_decoder_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
 }
 

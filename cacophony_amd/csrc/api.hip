@@ -862,6 +862,136 @@ int caco_decoder_forward(caco_model* m, const float* text_hidden, const int64_t*
   return CACO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Incremental caption decoding with key / value caches: the JAX path's get_next_decoder_logits loop
+// (src/caco/caco.py:154-230).  Both stacks are causal, so the keys and values of earlier caption positions never
+// change: a step embeds ONE new token per clip, runs it through the 12 text layers and the decoder layers against the
+// cached rows, appends its own K | V rows, and projects the last hidden state to the vocabulary.  The cross-attention
+// keys / values of the audio tokens are computed once per clip batch.  Same kernels as the full-prefix form
+// (caco_text_forward + caco_decoder_forward), which it reproduces position by position.
+// ------------------------------------------------------------------------------------------------
+struct caco_decode_state {
+  caco_model* m = nullptr;
+  int batch = 0, seq_a = 0, max_len = 0, pos = 0;
+  std::vector<bf16_t*> text_kv, dec_kv, cross_kv;     // [layers] x [B, max_len, 2H] / [B*S, 2H]
+  float* audio_mask = nullptr;                        // [B, S] copy
+  char* ws = nullptr;                                 // per-step scratch
+  size_t ws_bytes = 0;
+  std::vector<void*> owned;
+};
+
+void caco_decode_end(caco_decode_state* s) {
+  if (!s) return;
+  for (void* p : s->owned) (void)hipFree(p);
+  delete s;
+}
+
+int caco_decode_begin(caco_model* m, const float* audio_hidden, const float* audio_mask, int32_t batch, int32_t seq_audio,
+                      int32_t max_len, caco_decode_state** out, void* stream) {
+  CACO_REQUIRE(m && m->finalized && out, "caco_decode_begin: bad arguments");
+  CACO_REQUIRE(!m->dlayers.empty() && m->dec_proj.w, "Decoder module not initialized");
+  CACO_REQUIRE(audio_hidden && audio_mask && batch > 0 && seq_audio > 0 && max_len > 0, "caco_decode_begin: bad arguments");
+  CACO_REQUIRE(max_len <= m->cfg.text_max_pos, "caco_decode_begin: max_len %d exceeds max_position_embeddings %d", max_len, m->cfg.text_max_pos);
+  hipStream_t st = (hipStream_t)stream;
+  const caco_config& c = m->cfg;
+  const int H = c.text_hidden, I = c.text_intermediate, Vp = m->dec_proj.out;
+  const int64_t Ma = (int64_t)batch * seq_audio;
+  caco_decode_state* s = new (std::nothrow) caco_decode_state();
+  CACO_REQUIRE(s, "caco_decode_begin: out of host memory");
+  s->m = m; s->batch = batch; s->seq_a = seq_audio; s->max_len = max_len;
+  auto dev = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    s->owned.push_back(p);
+    return p;
+  };
+  bool ok = true;
+  const size_t cache_bytes = (size_t)batch * max_len * 2 * H * 2;
+  for (size_t n = 0; n < m->tlayers.size() && ok; ++n) { s->text_kv.push_back((bf16_t*)dev(cache_bytes)); ok = s->text_kv.back() != nullptr; }
+  for (size_t n = 0; n < m->dlayers.size() && ok; ++n) { s->dec_kv.push_back((bf16_t*)dev(cache_bytes)); ok = s->dec_kv.back() != nullptr; }
+  for (size_t n = 0; n < m->dlayers.size() && ok; ++n) { s->cross_kv.push_back((bf16_t*)dev((size_t)Ma * 2 * H * 2)); ok = s->cross_kv.back() != nullptr; }
+  s->audio_mask = ok ? (float*)dev((size_t)Ma * 4) : nullptr;
+  // per-step scratch: x, y fp32 [B,H]; xb, o bf16 [B,H]; qkv bf16 [B, qkv_ld]; a bf16 [B,I]; logits fp32 [B,Vp]
+  s->ws_bytes = (size_t)batch * ((size_t)H * 4 * 2 + (size_t)H * 2 * 2 + (size_t)qkv_ld(H) * 2 + (size_t)I * 2 + (size_t)Vp * 4) + 4096;
+  s->ws = ok && s->audio_mask ? (char*)dev(s->ws_bytes) : nullptr;
+  bf16_t* ab = ok && s->ws ? (bf16_t*)dev((size_t)Ma * H * 2) : nullptr;       // bf16 audio rows (only needed here)
+  if (!ok || !s->audio_mask || !s->ws || !ab) {
+    caco_decode_end(s);
+    set_error("caco_decode_begin: out of device memory");
+    return CACO_ERR_HIP;
+  }
+  int rc = CACO_OK;
+  if (hipMemcpyAsync(s->audio_mask, audio_mask, (size_t)Ma * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = CACO_ERR_HIP;
+  if (!rc) rc = cast_f32_to_bf16(audio_hidden, ab, Ma * H, st);
+  for (size_t n = 0; n < m->dlayers.size() && !rc; ++n) rc = linear_bf16(m->dlayers[n].ckv, ab, Ma, ACT_NONE, s->cross_kv[n], st);
+  if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = CACO_ERR_HIP;         // `ab` is released below
+  if (rc) {
+    caco_decode_end(s);
+    return rc;
+  }
+  (void)hipFree(ab);
+  s->owned.pop_back();
+  *out = s;
+  return CACO_OK;
+}
+
+// token_ids int64 [B] = the token at position s->pos of every clip (BOS at the first call); logits fp32 [B, vocab] = the
+// decoder's distribution over the NEXT token.
+int caco_decode_step(caco_decode_state* s, const int64_t* token_ids, float* logits, void* stream) {
+  CACO_REQUIRE(s && s->m && token_ids && logits, "caco_decode_step: bad arguments");
+  CACO_REQUIRE(s->pos < s->max_len, "caco_decode_step: position %d reached max_len %d", s->pos, s->max_len);
+  caco_model* m = s->m;
+  hipStream_t st = (hipStream_t)stream;
+  const caco_config& c = m->cfg;
+  const int H = c.text_hidden, I = c.text_intermediate, V = c.text_vocab, Vp = m->dec_proj.out;
+  const int heads = c.text_heads, hd = H / heads, B = s->batch, ldq = qkv_ld(H), pos = s->pos, T = pos + 1;
+  char* w = s->ws;
+  auto take = [&](size_t bytes) { char* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
+  float* x = (float*)take((size_t)B * H * 4);
+  float* y = (float*)take((size_t)B * H * 4);
+  bf16_t* xb = (bf16_t*)take((size_t)B * H * 2);
+  bf16_t* o = (bf16_t*)take((size_t)B * H * 2);
+  bf16_t* qkv = (bf16_t*)take((size_t)B * ldq * 2);
+  bf16_t* a = (bf16_t*)take((size_t)B * I * 2);
+  float* lg = (float*)take((size_t)B * Vp * 4);
+  CACO_REQUIRE((size_t)(w - s->ws) <= s->ws_bytes, "caco_decode_step: scratch overflow");
+  // one layer's self-attention on the new rows: fused QKV, K | V appended to the cache, one query per clip against T keys
+  auto self_attn = [&](const TextLayer& L, bf16_t* cache) -> int {
+    CACO_TRY(linear_bf16(L.qkv, xb, B, ACT_NONE, qkv, st, ldq));
+    CACO_HIP(hipMemcpy2DAsync(cache + (size_t)pos * 2 * H, (size_t)s->max_len * 2 * H * 2, qkv + H, (size_t)ldq * 2, (size_t)2 * H * 2, (size_t)B,
+                              hipMemcpyDeviceToDevice, st));
+    CACO_TRY(attention_qkv(qkv, ldq, 1, cache, 2 * H, 0, H, nullptr, B, T, heads, hd, 0, o, st, s->max_len));
+    CACO_TRY(linear_f32(L.attn_out, o, B, x, y, st));
+    return layernorm(y, L.ln_attn.g, L.ln_attn.b, B, H, c.text_ln_eps, x, xb, st);
+  };
+  auto mlp = [&](const TextLayer& L) -> int {
+    CACO_TRY(linear_bf16(L.inter, xb, B, ACT_GELU, a, st));
+    CACO_TRY(linear_f32(L.out, a, B, x, y, st));
+    return layernorm(y, L.ln_out.g, L.ln_out.b, B, H, c.text_ln_eps, x, xb, st);
+  };
+  // text tower on the new token (RobertaEmbeddings + 12 causal layers; every prefix token is kept, as in the reference's loop)
+  CACO_STAGE("decode.embed_ln", text_embed_ln(token_ids, nullptr, m->word, m->pos, m->type0, m->emb_ln.g, m->emb_ln.b, B, 1, H, c.text_vocab,
+                                              c.text_max_pos, c.text_ln_eps, x, xb, st, pos));
+  for (size_t n = 0; n < m->tlayers.size(); ++n) {
+    CACO_STAGE("decode.text_layer", self_attn(m->tlayers[n], s->text_kv[n]));
+    CACO_STAGE("decode.text_layer", mlp(m->tlayers[n]));
+  }
+  // decoder layers: self-attention (cache), cross-attention over the audio tokens (keys / values from caco_decode_begin), MLP
+  for (size_t n = 0; n < m->dlayers.size(); ++n) {
+    const DecLayer& L = m->dlayers[n];
+    CACO_STAGE("decode.dec_layer", self_attn(L.t, s->dec_kv[n]));
+    CACO_STAGE("decode.dec_layer", linear_bf16(L.cq, xb, B, ACT_NONE, qkv, st));
+    CACO_STAGE("decode.dec_layer", attention_qkv(qkv, H, 1, s->cross_kv[n], 2 * H, 0, H, s->audio_mask, B, s->seq_a, heads, hd, 0, o, st));
+    CACO_STAGE("decode.dec_layer", linear_f32(L.cattn_out, o, B, x, y, st));
+    CACO_STAGE("decode.dec_layer", layernorm(y, L.ln_cross.g, L.ln_cross.b, B, H, c.text_ln_eps, x, xb, st));
+    CACO_STAGE("decode.dec_layer", mlp(L.t));
+  }
+  CACO_STAGE("decode.vocab", linear_f32(m->dec_proj, xb, B, nullptr, lg, st));
+  CACO_HIP(hipMemcpy2DAsync(logits, (size_t)V * 4, lg, (size_t)Vp * 4, (size_t)V * 4, (size_t)B, hipMemcpyDeviceToDevice, st));
+  s->pos = T;
+  return CACO_OK;
+}
+
 int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float* emb,
                       void* stream) {
   CACO_TRY(check_audio_shapes(m, batch, max_patches));

@@ -58,7 +58,7 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
 template <int HD, bool CAUSAL, int NW>
 __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, int q_ld, int Sq, const bf16_t* __restrict__ kv, int ld,
                                                int k_off, int v_off, const float* __restrict__ key_mask, int S, int heads,
-                                               bf16_t* __restrict__ out, float scale_log2) {
+                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
   constexpr int NT = NW * 64, QB = NW * 32;
   constexpr int RP = HD * 2;                   // K and V row pitch in LDS = the unpadded row (192 / 128 bytes)
   constexpr int VP = RP;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   // columns k_off / v_off past the head's first column.  Self-attention passes the same buffer twice (Sq == S).
   const int64_t row_base = (int64_t)b * S, qrow_base = (int64_t)b * Sq;
   const bf16_t* q_base = qp_ + qrow_base * q_ld + h * HD;
-  const bf16_t* kv_base = kv + row_base * ld + h * HD;
+  const bf16_t* kv_base = kv + (int64_t)b * kv_rows * ld + h * HD;    // kv_rows >= S: rows between two clips' keys (a KV cache)
 
   const int q0 = qb * QB + wave * 32;
   const int q_row = q0 + l31;
@@ -304,8 +304,8 @@ template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64, ATTN_OCC) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
-                                                               bf16_t* __restrict__ out, float scale_log2) {
-  attention_body<HD, CAUSAL, NW>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2);
+                                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
+  attention_body<HD, CAUSAL, NW>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows);
 }
 
 }  // namespace
@@ -322,14 +322,16 @@ int set_attention64(int on) {
 
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st) {
-  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st);
+  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0);
 }
 
 // General form: queries [batch, seq_q] rows of `q` (row stride q_ld, head h at column h*head_dim), keys / values
 // [batch, seq] rows of `kv` (row stride ld, head h at columns h*head_dim + k_off / v_off).  Cross-attention of the caption
 // decoder (RobertaSelfAttention with key_value_states, src/caco_torch/text_models/roberta.py:67-104): seq_q != seq.
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask,
-                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st) {
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows) {
+  if (kv_batch_rows <= 0) kv_batch_rows = seq;
+  CACO_REQUIRE(kv_batch_rows >= seq, "attention: kv_batch_rows %d < seq %d", kv_batch_rows, seq);
   CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);
   CACO_REQUIRE(!causal || seq_q == seq, "attention: the causal mask needs seq_q == seq (%d vs %d)", seq_q, seq);
   CACO_REQUIRE(q_ld % 8 == 0, "attention: query row stride must be a multiple of 8 elements");
@@ -339,7 +341,7 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   {   // Opt-in experiment (CACO_ATTN64=1): the two-pass 64-rows-per-wave kernel of attention64.hip for non-causal shapes.
       // Same results (same tests), measured 10 % SLOWER than this kernel at the encoder shape (460 vs 415 us) and 20 % at
       // S = 1500: see the header of attention64.hip and DESIGN.md 4.2 for the cycle anatomy.
-    if (attention64_enabled() && !causal && seq_q >= 128) return attention64(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, out, st);
+    if (attention64_enabled() && !causal && seq_q >= 128 && kv_batch_rows == seq) return attention64(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, out, st);
   }
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
@@ -348,7 +350,7 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   constexpr int NW = 4;
   const dim3 grid((seq_q + NW * 32 - 1) / (NW * 32), heads, batch);
 #define CACO_ATTN(HD_, C_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2)
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows)
   if (head_dim == 96) {
     if (causal) CACO_ATTN(96, true); else CACO_ATTN(96, false);
   } else {

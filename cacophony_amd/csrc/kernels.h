@@ -45,7 +45,7 @@ int layernorm(const float* x, const float* gamma, const float* beta, int64_t row
 int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st);
 int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                   const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
-                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st);
+                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st, int pos_base = 0);   // position = row % seq + pos_base
 // x[m, :] (+)= sincos(time[m]) + freq_table[freq[m], :] (+ base[:] when base != null, replacing x)
 int add_pos_embed(float* x, const float* base, const float* time_inds, const float* freq_inds, const float* freq_table,
                   int64_t rows, int dim, int num_freq, hipStream_t st);
@@ -61,8 +61,9 @@ int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq,
 // qkv: bf16 [batch*seq, ld], Q at column 0, K at k_off, V at v_off (head h = columns h*head_dim.. of each)
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st);
+// kv_batch_rows: rows between the first keys of two consecutive clips in `kv` (0 = seq; larger for a KV cache)
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
-                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st);
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows = 0);
 
 int attention64_enabled();
 int set_attention64(int on);

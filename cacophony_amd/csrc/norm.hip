@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const int64_t* __res
                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int64_t rows, int seq, int dim,
                                                             int vocab, int max_pos, float eps, float* __restrict__ of,
-                                                            bf16_t* __restrict__ ob) {
+                                                            bf16_t* __restrict__ ob, int pos_base) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   int64_t id = ids[row];
-  int64_t pi = pos_ids ? pos_ids[row] : (row % seq);
+  int64_t pi = pos_ids ? pos_ids[row] : (row % seq) + pos_base;
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);        // host validates; clamp keeps a bad id from faulting
   pi = pi < 0 ? 0 : (pi >= max_pos ? max_pos - 1 : pi);
   const int nchunk = dim >> 2;
@@ -254,10 +254,10 @@ int row_stats_bf16(const float* x, int64_t rows, int dim, float eps, bf16_t* xb,
 
 int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                   const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
-                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st) {
+                  float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st, int pos_base) {
   CACO_REQUIRE(dim % 4 == 0 && dim <= 256 * MAXC, "text_embed_ln: unsupported dim %d", dim);
   hipLaunchKernelGGL(text_embed_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, ids, pos_ids, word, pos,
-                     type0, gamma, beta, rows, seq, dim, vocab, max_pos, eps, out_f32, out_bf16);
+                     type0, gamma, beta, rows, seq, dim, vocab, max_pos, eps, out_f32, out_bf16, pos_base);
   return check_hip(hipGetLastError(), "text_embed_ln launch");
 }
 

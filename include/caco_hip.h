@@ -149,6 +149,20 @@ int caco_decoder_forward(caco_model* m, const float* text_hidden_dev, const int6
                          const float* audio_hidden_dev, const float* audio_mask_dev, int32_t batch, int32_t seq_text,
                          int32_t seq_audio, float* logits_dev, void* stream);
 
+/* ---- incremental caption decoding with key / value caches: the JAX path's get_next_decoder_logits loop
+ * (src/caco/caco.py:154-230; the torch path re-runs the whole prefix every step, eval_caco_torch.py:443-456).
+ * caco_decode_begin projects the audio hidden states to every decoder layer's cross-attention keys / values once and
+ * allocates the self-attention caches of the 12 text layers and the decoder layers for captions of up to max_len tokens;
+ * caco_decode_step feeds ONE token per clip (token_ids_dev int64 [B]: BOS first, then the token chosen from the previous
+ * step's logits) and returns logits_dev fp32 [B, vocab] for the next position - equal, position by position, to
+ * caco_text_forward + caco_decoder_forward on the prefix with an all-ones text mask; caco_decode_end frees the state.
+ * The state owns its device memory; the model must outlive it; steps of one state must be issued in order on one stream. */
+typedef struct caco_decode_state caco_decode_state;
+int caco_decode_begin(caco_model* m, const float* audio_hidden_dev, const float* audio_mask_dev, int32_t batch,
+                      int32_t seq_audio, int32_t max_len, caco_decode_state** out, void* stream);
+int caco_decode_step(caco_decode_state* s, const int64_t* token_ids_dev, float* logits_dev, void* stream);
+void caco_decode_end(caco_decode_state* s);
+
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 int64_t caco_workspace_bytes(const caco_model* m);
 /* Tuning knob: bf16 GEMM kernel choice.  256 (default) = the 256x128 two-workgroups-per-CU kernel when its grid

@@ -203,3 +203,35 @@ def test_decoder_full_vocabulary():
     keep = tmask.astype(bool)
     assert rel_l2(got[keep], ref[keep]) < LOGIT_TOL
     assert cosine_rows(got[keep], ref[keep]).min() > COS_TOL
+
+
+@pytest.mark.gpu
+def test_cached_decode_steps_equal_full_prefix(dec_model):
+    """caco_decode_step (key / value caches) against the full-prefix form position by position, and against the
+    reference's own logits for the 12-token prefix (decoder_tiny.npz)."""
+    from cacophony_amd import captioning, frontend
+    g = load_golden("decoder_tiny.npz")
+    wav = synth.make_waveforms(2, start=40)
+    ab = frontend.mel_patches_device(torch.from_numpy(wav).cuda(), 500, torch.float32)
+    _, ah = dec_model.get_audio_embedding(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"])
+    ids = torch.from_numpy(g["ids"][:, :12]).cuda()
+    full = dec_model.get_decoder_logits(ah, ab["audio_mask"], ids, torch.ones_like(ids)).cpu().numpy()       # [2, 12, V]
+    st = captioning.CaptionDecodeState(dec_model, ah, ab["audio_mask"], max_len=16)
+    steps = np.stack([st.step(ids[:, p]).cpu().numpy() for p in range(12)], axis=1)
+    assert steps.shape == full.shape
+    for p in range(12):
+        assert rel_l2(steps[:, p], full[:, p]) < 3e-3, p          # same arithmetic, different GEMM tilings (M = 2 vs 24)
+    assert rel_l2(steps[:, -1], g["logits_prefix12_last"]) < LOGIT_TOL
+    assert cosine_rows(steps[:, -1], g["logits_prefix12_last"]).min() > COS_TOL
+    with pytest.raises(ValueError):
+        st.step(ids[:1, 0])
+    for p in range(4):
+        st.step(ids[:, p])
+    with pytest.raises((ValueError, RuntimeError), match="max_len"):
+        st.step(ids[:, 0])
+    st.close()
+    # the decoding loop gives the same tokens with and without the caches (greedy)
+    a_ids = captioning.decode_caption_ids(dec_model, ab, max_decode_length=6, greedy=True, use_cache=True).cpu().numpy()
+    b_ids = captioning.decode_caption_ids(dec_model, ab, max_decode_length=6, greedy=True, use_cache=False).cpu().numpy()
+    n = min(a_ids.shape[1], b_ids.shape[1])
+    assert (a_ids[:, :min(n, 4)] == b_ids[:, :min(n, 4)]).all()

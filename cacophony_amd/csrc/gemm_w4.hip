@@ -495,18 +495,25 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
     const int voff = rrow * rowb + c8 * 16;
     const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
         produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
-    u32x4 res[2][4];
+#ifndef W8_RES_AHEAD
+#define W8_RES_AHEAD 1      // residual slabs in flight ahead of the one being processed (2 and 3 measured: no gain)
+#endif
+    constexpr int RA = W8_RES_AHEAD, RN = RA + 1;
+    u32x4 res[RN][4];
     float st1[4][4], st2[4][4];
     auto fetch = [&](int s, u32x4 (&dst)[4]) {
       const int i = s >> 1, j = s & 1;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
     };
-    if (has_resid) fetch(0, res[0]);
+    if (has_resid) {
+#pragma unroll
+      for (int s0 = 0; s0 < RA; ++s0) fetch(s0, res[s0 % RN]);
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int i = s >> 1, j = s & 1;
-      if (has_resid && s + 1 < 8) fetch(s + 1, res[(s + 1) & 1]);
+      if (has_resid && s + RA < 8) fetch(s + RA, res[(s + RA) % RN]);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v;
@@ -519,7 +526,7 @@ __device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const Gem
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
-        if (has_resid) v += __builtin_bit_cast(f32x4, res[s & 1][tt]);
+        if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
         if (produce_xb) {         // bf16 copy of the new rows: the next (LayerNorm-folded) GEMM's A operand, default cache policy
           bf16x4 b;

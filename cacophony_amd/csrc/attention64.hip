@@ -75,6 +75,11 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ qp_,
   const bf16_t* q_base = qp_ + qrow_base * q_ld + h * HD;
   const bf16_t* kv_base = kv + row_base * ld + h * HD;
   const int q0 = qb * QB + wave * 64;          // block A = rows q0 .. q0+31, block B = q0+32 .. q0+63
+#ifdef ATTN64_PRIO
+  // the second wave of every SIMD (waves NW/2 ..) measured up to 1.7x slower than the first in the mixed regions
+  // (oldest-first arbitration): give it the higher issue priority.  Measured with 1 and 3: no effect on the kernel time.
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(ATTN64_PRIO);
+#endif
 
   // Q block of this wave (64 rows x HD) -> its own LDS region by DMA, in the K tile's swizzled row format; the B-operand
   // fragments are re-read from there every tile instead of occupying 2 * KS * 4 registers for the whole kernel (with

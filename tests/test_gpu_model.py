@@ -287,3 +287,16 @@ def test_rccl_gather_path_single_rank(full_model):
         assert (block - similarity(ea, et)).abs().max().item() == 0.0
     finally:
         dist.destroy_process_group()
+
+
+def test_odd_batch_sizes_select_different_kernels_same_result(full_model):
+    """Batch 1 / 5 / 33 take the small-M GEMM kernels, batch 40 the persistent ones: a clip's embedding must not depend on
+    who it is batched with (measured: bitwise equal; bar 1e-5)."""
+    wav = torch.from_numpy(synth.make_waveforms(40, start=300)).to(DEV)
+    ids, mask = synth.make_captions(40, 32, 50265, start=300)
+    ra, rt = full_model.encode_pairs(wav, ids, mask, 500)
+    ra, rt = ra.cpu().numpy(), rt.cpu().numpy()
+    for b in (1, 5, 33):
+        ea, et = full_model.encode_pairs(wav[:b], ids[:b], mask[:b], 500)
+        assert np.abs(ea.cpu().numpy() - ra[:b]).max() < 1e-5, b
+        assert np.abs(et.cpu().numpy() - rt[:b]).max() < 1e-5, b

@@ -238,6 +238,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0's un-timed profile pass is over: every rank tears the group down together
         dist.destroy_process_group()
 
 

@@ -361,6 +361,8 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   if (cfg == 9256 && gemm_bf16_v8_ok(p, epi)) return gemm_bf16_v8(p, epi, act, st);
   if ((cfg == 4256 || cfg == 8256) && gemm_bf16_w4_ok(p, epi)) return gemm_bf16_w4(p, epi, act, cfg == 8256 ? 8 : 4, st);
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
+  if (cfg == 5256 && gemm_bf16_d4_ok(p, epi)) return gemm_bf16_d4(p, epi, act, st);
+  if (cfg == 6256 && gemm_bf16_s8_ok(p, epi)) return gemm_bf16_s8(p, epi, act, st);
   if (cfg == 256) {
     // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w4.hip; most reuse per L2 byte, measured
     // 2-10 % faster than the phased kernel below on the encoder shapes) when every CU gets >= 2 tiles,
@@ -386,7 +388,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256 || tile == 4256 || tile == 8256 || tile == 9256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256 || tile == 4256 || tile == 8256 || tile == 9256 || tile == 5256 || tile == 6256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
   return gemm_tile_config();
 }
 

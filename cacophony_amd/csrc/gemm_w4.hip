@@ -32,6 +32,7 @@
 // text_models/roberta.py:62-64,110,153,164; caco.py:35-37).
 #include "common.h"
 #include "kernels.h"
+#include "gemm_w8_epilogue.h"
 
 namespace caco {
 namespace {
@@ -45,7 +46,6 @@ constexpr int W_SMEM = 5 * W_SLOT;            // 163840 = 160 KiB
 constexpr int W_SLAB = 8192;                  // per-wave epilogue slab inside a dead A slot
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef W4_NOREADS
 #define W4_DO_READS 0
@@ -60,13 +60,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_SGB_MFMA 0x008
 #define W4_SGB_VMEM 0x010
 #define W4_SGB_DSRD 0x100
-
-template <int ACT>
-__device__ __forceinline__ float w4_epi_act(float x) {
-  if constexpr (ACT == ACT_SILU) return silu_f(x);
-  if constexpr (ACT == ACT_GELU) return gelu_erf_f(x);
-  return x;
-}
 
 // Tile order.  The n-tiles are processed in groups of G (p.ngroup): all M panels of one group, then the next group,
 // n fastest inside a group.  A group's weight rows (G x 256 x K bf16) then stay in the XCD's 4 MiB L2 for the whole
@@ -377,6 +370,21 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
 //   per wave and 16-deep step: 8 MFMAs, 6 fragment reads (x0 w0 x1 w1 x2 x3)
 //   per wave and K-tile: 4 A pieces (ks1, ks2) + 4 W pieces (ks3); s_waitcnt vmcnt(4) leaves A(g+2) in flight at the barrier
 // ================================================================================================
+#ifdef W8_NOMFMA      // ablation: the K-loop's memory side alone (DMA + fragment reads + barriers), no matrix instructions
+#define W8_MFMAS(XC, WC)                                                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) asm volatile("" ::"v"(XC[q_]));               \
+  asm volatile("" ::"v"(WC[0]), "v"(WC[1]));
+#else
+#define W8_MFMAS(XC, WC)                                                                         \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[0], acc[0][0], 0, 0, 0);         \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[1], acc[1][0], 0, 0, 0);         \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[0], acc[0][1], 0, 0, 0);         \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[1], acc[1][1], 0, 0, 0);         \
+  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[2], acc[2][0], 0, 0, 0);         \
+  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[2], acc[2][1], 0, 0, 0);         \
+  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[3], acc[3][0], 0, 0, 0);         \
+  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[3], acc[3][1], 0, 0, 0);
+#endif
 #define W8_STEP(XN, WN, XA, WW, KS, XC, WC, DMA0, DMA1, DMA2, DMA3)                               \
   if (W4_DO_READS) {                                                                             \
     XN[0] = w4_frag(XA, 0 * 32 + frow, (KS) * 2 + fhalf);                                        \
@@ -392,14 +400,7 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
   DMA2;                                                                                          \
   if (W4_DO_READS) XN[3] = w4_frag(XA, 3 * 32 + frow, (KS) * 2 + fhalf);                         \
   DMA3;                                                                                          \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[0], acc[0][0], 0, 0, 0);         \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[1], acc[1][0], 0, 0, 0);         \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[0], acc[0][1], 0, 0, 0);         \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[1], acc[1][1], 0, 0, 0);         \
-  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[2], acc[2][0], 0, 0, 0);         \
-  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[2], acc[2][1], 0, 0, 0);         \
-  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[3], acc[3][0], 0, 0, 0);         \
-  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[3], acc[3][1], 0, 0, 0);         \
+  W8_MFMAS(XC, WC)                                                                               \
   _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_) {                                             \
     __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                     \
     if (n_ < 6) __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                         \
@@ -407,162 +408,20 @@ __device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
   }                                                                                              \
   __builtin_amdgcn_sched_barrier(0);
 
-// Epilogue of one 256x256 tile, this wave's 128 x 64 part.  MODE selects what is known at compile time, so that the hot
-// forms carry no per-element branches or phi copies (the generic form measured 400 v_mov + 70 branches per tile):
-//   0 generic: bias / residual / LayerNorm-fold consumer / producer outputs all tested at run time
-//   1 bias only        2 bias + residual (EPI_F32)
-//   3 bias + LayerNorm-fold consumer (EPI_BF16)        4 bias + residual + fold producer (EPI_F32: bf16 copy + row sums)
-// Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
-// fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
-// (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
-// the epilogue - is 30-40 % SLOWER on the QKV / fc1 shapes: partial-line writes from 32 rows per instruction.)
-// Cache-policy bits of the epilogue's stores / residual loads: 2 = nt (streaming).  The outputs are far larger than the
-// L2 and are not re-read by this kernel; marking them streaming keeps the weight / activation tiles of the K-loop
-// resident instead: QKV -5 %, fc1 -4.6 %, out-proj -5.8 % (nt residual loads), fc2 +-0; sc0 / sc1 variants equal.
-#ifndef W8_ST_AUX
-#define W8_ST_AUX 2
-#endif
-#ifndef W8_LD_AUX
-#define W8_LD_AUX 2
-#endif
-template <int EPI, int ACT, int MODE>
-__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
-  const int lm = lane & 31, lh = lane >> 5;
-  const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
-  const int64_t mw = m0 + wm * 128;
-  const int nw = n0 + wn * 64;
-  const int rows = (int)min((int64_t)128, p.M - mw);    // valid rows of this wave's part (may be <= 0)
-  const bool has_bias = MODE ? true : p.bias != nullptr;
-  if constexpr (EPI == EPI_BF16) {
-    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7).
-    // Bias (and the LayerNorm-fold column sums) are re-read from L1 per 4-column group instead of being held in 32-64
-    // registers across the whole epilogue: the accumulators already fill half the register file.
-    const int rowb = p.ldc * 2;
-    const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
-    const int voff = rrow * rowb + c8 * 16;
-    const bool fold = MODE ? MODE == 3 : p.fold_mr != nullptr;      // LayerNorm folded into this GEMM (kernels.h)
-    const float* bias_l = has_bias ? p.bias + nw + lh * 4 : nullptr;
-    const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float nmr = 0.f, rstd = 1.f;                   // out = rstd * acc + (-mean * rstd) * c1 + bias
-      if (fold) {
-        const int64_t m = min(mw + i * 32 + lm, p.M - 1);
-        const float2 mr = *reinterpret_cast<const float2*>(p.fold_mr + 2 * m);
-        rstd = mr.y;
-        nmr = -mr.x * mr.y;
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 bb = has_bias ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-          if (fold) {
-            const f32x4 cc = *reinterpret_cast<const f32x4*>(c1_l + j * 32 + g * 8);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bb[r] = __builtin_fmaf(nmr, cc[r], bb[r]);
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x = MODE == 1 ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
-            o[r] = (bf16_t)w4_epi_act<ACT>(x);
-          }
-          *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
-        }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int row = tt * 8 + rrow;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
-#ifdef W4_NOSTORE
-        if (v[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, 0);
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, W8_ST_AUX);
-#endif
-      }
-    }
-  } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
-    const int rowb = p.ldc * 4;
-    const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
-    const bool has_resid = MODE ? (MODE == 2 || MODE == 4) : p.resid != nullptr;
-    const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
-    const bool produce_st = MODE ? MODE == 4 : p.stats_part != nullptr;
-    const __amdgpu_buffer_rsrc_t out_r =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
-    const int voff = rrow * rowb + c8 * 16;
-    const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
-        produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
-#ifndef W8_RES_AHEAD
-#define W8_RES_AHEAD 1      // residual slabs in flight ahead of the one being processed (2 and 3 measured: no gain)
-#endif
-    constexpr int RA = W8_RES_AHEAD, RN = RA + 1;
-    u32x4 res[RN][4];
-    float st1[4][4], st2[4][4];
-    auto fetch = [&](int s, u32x4 (&dst)[4]) {
-      const int i = s >> 1, j = s & 1;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
-    };
-    if (has_resid) {
-#pragma unroll
-      for (int s0 = 0; s0 < RA; ++s0) fetch(s0, res[s0 % RN]);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = s >> 1, j = s & 1;
-      if (has_resid && s + RA < 8) fetch(s + RA, res[(s + RA) % RN]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
-        if (has_bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
-        *reinterpret_cast<f32x4*>(slab + lm * 128 + (((g * 2 + lh) ^ (lm & 7)) << 4)) = v;
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int row = tt * 8 + rrow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
-        if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
-        if (produce_xb) {         // bf16 copy of the new rows: the next (LayerNorm-folded) GEMM's A operand, default cache policy
-          bf16x4 b;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
-          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff >> 1), ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
-        }
-        if (produce_st) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
-          const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
-          const float a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-          if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
-        }
-      }
-    }
-    if (produce_st) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
-      const int nslot = p.N >> 6, slot = nw >> 6;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          float a1 = st1[i][tt], a2 = st2[i][tt];
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) {
-            a1 += __shfl_xor(a1, o, 64);
-            a2 += __shfl_xor(a2, o, 64);
-          }
-          const int64_t m = mw + i * 32 + tt * 8 + rrow;
-          if (c8 == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_part + (m * nslot + slot) * 2) = make_float2(a1, a2);
-        }
-    }
-  }
-}
-
 // (kernel bodies live in __device__ functions: the buffer-descriptor types they use are invisible to the host pass,
 // which otherwise drops the kernel's launch stub)
+// -DW8_TIMING (tools/w8_timing.py): wave 0 of every workgroup stamps s_memtime at the phase boundaries of each tile into
+// the 64-bit words that follow the output matrix (the tool allocates them): [wg][tile][0..4] = first in-loop barrier
+// passed, K-loop done, epilogue issued, post-epilogue barrier passed, (next tile's first barrier = stores retired)
+#ifdef W8_TIMING
+#define W8_STAMP(t, k)                                                                                      \
+  if (wave == 0 && lane == 0 && (t) < 32)                                                                   \
+    reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.out) +                                  \
+        (size_t)p.M * p.ldc * (EPI == EPI_BF16 ? 2 : 4))[((size_t)blockIdx.x * 32 + (t)) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define W8_STAMP(t, k)
+#endif
+
 template <int EPI, int ACT, int MODE>
 __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -579,6 +438,9 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   if (slot >= cnt) return;
   const int nk = p.K / WBK;
+  // De-synchronise the CUs: identical tiles would otherwise march in lock step, and every workgroup's epilogue (stores,
+  // residual loads) would hit HBM in the same few microseconds while the memory system idles during the K-loops.
+  for (int z = (slot & 31) * p.stagger >> 5; z > 0; --z) __builtin_amdgcn_s_sleep(16);
 
   const int frow = lane & 31, fhalf = lane >> 5;
   const int x_off = wm * 128 * WROWB, w_off = wn * 64 * WROWB;
@@ -615,10 +477,14 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_1, wave);
   advance_a();
+#ifdef W8_A2
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
 #pragma unroll
   for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_1, wave);
   advance_w();
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
   __builtin_amdgcn_s_barrier();
   bf16x8 x0[4], w0[2], x1[4], w1[2];
 #pragma unroll
@@ -632,6 +498,9 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   constexpr int NST = (EPI == EPI_BF16) ? 16 : 32;      // global stores per wave and epilogue (full tile)
   bool stores_pending = false;
   int c_li = slot;
+#ifdef W8_TIMING
+  int tile_no = 0;
+#endif
   while (true) {
     f32x16 acc[4][2];
 #pragma unroll
@@ -644,6 +513,14 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
     for (int kt = 0; kt < nk; ++kt) {
       const char* xa = smem + a_c + x_off;
       const char* ww = smem + w_c + w_off;
+#ifdef W8_A2
+      // experiment: A one K-tile ahead only (what a two-slot A ring allows): W(g+1) in ks0, A(g+2) in the previous ks3
+      W8_STEP(x1, w1, xa, ww, 1, x0, w0, w4_piece_w<8>(CW, 0, ldw, smem + w_1, wave), w4_piece_w<8>(CW, 1, ldw, smem + w_1, wave),
+              w4_piece_w<8>(CW, 2, ldw, smem + w_1, wave), w4_piece_w<8>(CW, 3, ldw, smem + w_1, wave))
+      advance_w();
+      W8_STEP(x0, w0, xa, ww, 2, x1, w1, (void)0, (void)0, (void)0, (void)0)
+      W8_STEP(x1, w1, xa, ww, 3, x0, w0, (void)0, (void)0, (void)0, (void)0)
+#else
       // ks0: compute (g,0), read (g,1)
       W8_STEP(x1, w1, xa, ww, 1, x0, w0, (void)0, (void)0, (void)0, (void)0)
       // ks1: compute (g,1), read (g,2); A(g+2) pieces 0..1
@@ -651,8 +528,13 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
       // ks2: compute (g,2), read (g,3); A(g+2) pieces 2..3
       W8_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a<8>(CA, 2, smem + a_2, wave), (void)0, w4_piece_a<8>(CA, 3, smem + a_2, wave), (void)0)
       advance_a();
+#endif
       // A(g+1) and W(g+1) have landed (only A(g+2), and right after an epilogue its stores, may still be in flight);
       // every wave is done reading A(g), W(g)
+#ifdef W8_A2
+      stores_pending = false;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
       if (stores_pending) {
         // the producer form (bf16 copy + row statistics) issues 80 stores: the counter saturates at 63, which still
         // retires everything older than the stores
@@ -662,15 +544,28 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
       } else {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       }
+#endif
       __builtin_amdgcn_s_barrier();
+#ifdef W8_TIMING
+      if (kt == 0) { W8_STAMP(tile_no, 0) }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // ks3: compute (g,3), read (g+1,0) (possibly of the next output tile); W(g+2) -> slot of W(g)
+#ifdef W8_A2
+      // A(g+2) -> the slot of A(g) (all of its fragments have been read): with two A slots this is the earliest point
+      W8_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_a<8>(CA, 0, smem + a_2, wave),
+              w4_piece_a<8>(CA, 1, smem + a_2, wave), w4_piece_a<8>(CA, 2, smem + a_2, wave), w4_piece_a<8>(CA, 3, smem + a_2, wave))
+      advance_a();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+#else
       W8_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w<8>(CW, 0, ldw, smem + w_c, wave),
               w4_piece_w<8>(CW, 1, ldw, smem + w_c, wave), w4_piece_w<8>(CW, 2, ldw, smem + w_c, wave),
               w4_piece_w<8>(CW, 3, ldw, smem + w_c, wave))
       advance_w();
       { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
       { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+#endif
     }
     const int t = base + c_li;
     int tm_, tn_;
@@ -683,9 +578,15 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
+    W8_STAMP(tile_no, 1)
     w8_epilogue<EPI, ACT, MODE>(acc, p, m_cur, n_cur, wm, wn, lane, smem + a_2 + wave * 4096);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W8_STAMP(tile_no, 2)
     __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+    W8_STAMP(tile_no, 3)
+#ifdef W8_TIMING
+    ++tile_no;
+#endif
     // the next tile's first fragments are re-read here (ks3 already fetched them once): this way they are not live
     // across the epilogue, which needs the registers
 #pragma unroll
@@ -740,13 +641,17 @@ int launch_w4(const GemmArgs& p, hipStream_t st) {
     num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
-  const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
+  static const int env_grid = getenv("CACO_W8_MAXGRID") ? atoi(getenv("CACO_W8_MAXGRID")) : 0;     // experiments: fewer CUs
+  const int cus = env_grid > 0 && env_grid < num_cu ? env_grid : num_cu;
+  const int grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus / 8 * 8;
   GemmArgs q = p;
   {   // n-tiles per L2 group.  Default: one group (n fastest over all of N).  Grouping was measured on the encoder
       // shapes (CACO_W_NGROUP = 2..6): within +-2 % - the weight re-reads it removes are served by the Infinity Cache.
     static const int env_g = getenv("CACO_W_NGROUP") ? atoi(getenv("CACO_W_NGROUP")) : 0;
     const int tiles_n = p.N / 256;
     q.ngroup = (env_g > 0 && env_g < tiles_n) ? env_g : tiles_n;
+    static const int env_s = getenv("CACO_W8_STAGGER") ? atoi(getenv("CACO_W8_STAGGER")) : 0;
+    q.stagger = (NWV == 8 && tiles > grid) ? env_s : 0;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), W_SMEM, st, q);
   return check_hip(hipGetLastError(), "gemm_bf16_w4 launch");

@@ -1,0 +1,175 @@
+// Epilogue of the 128 x 64 per-wave output tile (4 x 2 blocks of v_mfma_f32_32x32x16_bf16, operands swapped so that a lane
+// owns 4 consecutive n of one output row m), shared by the one-workgroup-per-CU 256x256 kernel (gemm_w4.hip, w8) and the
+// two-workgroups-per-CU 256x128 kernel (gemm_d4.hip).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace caco {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int ACT>
+__device__ __forceinline__ float w4_epi_act(float x) {
+  if constexpr (ACT == ACT_SILU) return silu_f(x);
+  if constexpr (ACT == ACT_GELU) return gelu_erf_f(x);
+  return x;
+}
+
+// Epilogue of one 256x256 tile, this wave's 128 x 64 part.  MODE selects what is known at compile time, so that the hot
+// forms carry no per-element branches or phi copies (the generic form measured 400 v_mov + 70 branches per tile):
+//   0 generic: bias / residual / LayerNorm-fold consumer / producer outputs all tested at run time
+//   1 bias only        2 bias + residual (EPI_F32)
+//   3 bias + LayerNorm-fold consumer (EPI_BF16)        4 bias + residual + fold producer (EPI_F32: bf16 copy + row sums)
+// Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
+// fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
+// (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
+// the epilogue - is 30-40 % SLOWER on the QKV / fc1 shapes: partial-line writes from 32 rows per instruction.)
+// Cache-policy bits of the epilogue's stores / residual loads: 2 = nt (streaming).  The outputs are far larger than the
+// L2 and are not re-read by this kernel; marking them streaming keeps the weight / activation tiles of the K-loop
+// resident instead: QKV -5 %, fc1 -4.6 %, out-proj -5.8 % (nt residual loads), fc2 +-0; sc0 / sc1 variants equal.
+#ifndef W8_ST_AUX
+#define W8_ST_AUX 2
+#endif
+#ifndef W8_LD_AUX
+#define W8_LD_AUX 2
+#endif
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
+  const int lm = lane & 31, lh = lane >> 5;
+  const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
+  const int64_t mw = m0 + wm * 128;
+  const int nw = n0 + wn * 64;
+  const int rows = (int)min((int64_t)128, p.M - mw);    // valid rows of this wave's part (may be <= 0)
+  const bool has_bias = MODE ? true : p.bias != nullptr;
+  if constexpr (EPI == EPI_BF16) {
+    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7).
+    // Bias (and the LayerNorm-fold column sums) are re-read from L1 per 4-column group instead of being held in 32-64
+    // registers across the whole epilogue: the accumulators already fill half the register file.
+    const int rowb = p.ldc * 2;
+    const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    const bool fold = MODE ? MODE == 3 : p.fold_mr != nullptr;      // LayerNorm folded into this GEMM (kernels.h)
+    const float* bias_l = has_bias ? p.bias + nw + lh * 4 : nullptr;
+    const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float nmr = 0.f, rstd = 1.f;                   // out = rstd * acc + (-mean * rstd) * c1 + bias
+      if (fold) {
+        const int64_t m = min(mw + i * 32 + lm, p.M - 1);
+        const float2 mr = *reinterpret_cast<const float2*>(p.fold_mr + 2 * m);
+        rstd = mr.y;
+        nmr = -mr.x * mr.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 bb = has_bias ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (fold) {
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(c1_l + j * 32 + g * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] = __builtin_fmaf(nmr, cc[r], bb[r]);
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = MODE == 1 ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
+            o[r] = (bf16_t)w4_epi_act<ACT>(x);
+          }
+          *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
+        }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+#ifdef W4_NOSTORE
+        if (v[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, 0);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, W8_ST_AUX);
+#endif
+      }
+    }
+  } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
+    const int rowb = p.ldc * 4;
+    const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
+    const bool has_resid = MODE ? (MODE == 2 || MODE == 4) : p.resid != nullptr;
+    const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
+    const bool produce_st = MODE ? MODE == 4 : p.stats_part != nullptr;
+    const __amdgpu_buffer_rsrc_t out_r =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
+        produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
+#ifndef W8_RES_AHEAD
+#define W8_RES_AHEAD 1      // residual slabs in flight ahead of the one being processed (2 and 3 measured: no gain)
+#endif
+    constexpr int RA = W8_RES_AHEAD, RN = RA + 1;
+    u32x4 res[RN][4];
+    float st1[4][4], st2[4][4];
+    auto fetch = [&](int s, u32x4 (&dst)[4]) {
+      const int i = s >> 1, j = s & 1;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
+    };
+    if (has_resid) {
+#pragma unroll
+      for (int s0 = 0; s0 < RA; ++s0) fetch(s0, res[s0 % RN]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int i = s >> 1, j = s & 1;
+      if (has_resid && s + RA < 8) fetch(s + RA, res[(s + RA) % RN]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
+        if (has_bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
+        *reinterpret_cast<f32x4*>(slab + lm * 128 + (((g * 2 + lh) ^ (lm & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+        if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
+        if (produce_xb) {         // bf16 copy of the new rows: the next (LayerNorm-folded) GEMM's A operand, default cache policy
+          bf16x4 b;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff >> 1), ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
+        }
+        if (produce_st) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
+          const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
+        }
+      }
+    }
+    if (produce_st) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
+      const int nslot = p.N >> 6, slot = nw >> 6;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float a1 = st1[i][tt], a2 = st2[i][tt];
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+          }
+          const int64_t m = mw + i * 32 + tt * 8 + rrow;
+          if (c8 == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_part + (m * nslot + slot) * 2) = make_float2(a1, a2);
+        }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace caco

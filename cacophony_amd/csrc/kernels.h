@@ -18,6 +18,7 @@ struct GemmArgs {
   int N, K, ldc;
   int lda, ldw;         // row strides of A / W in elements; 0 = K (dense)
   int ngroup;           // gemm_x: n-tiles per L2 group (0 = all)
+  int stagger;          // persistent kernels: spread of the workgroups' start times, units of 1024 cycles (0 = none)
   // LayerNorm folding (8-wave kernel of gemm_w4.hip only; all null = plain GEMM).
   // consumer, EPI_BF16:  out = act( rstd[m] * (acc[m,n] - mean[m] * fold_c1[n]) + bias[n] )
   //   with A = the RAW (un-normalised) rows in bf16, W = gamma-scaled weights, bias = W.beta + b  (see api.hip)
@@ -34,6 +35,10 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w4_ok(const GemmArgs& p, int epi);                         // gemm_w4.hip
 int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st);   // waves: 4 or 8
+bool gemm_bf16_d4_ok(const GemmArgs& p, int epi);                         // gemm_d4.hip
+int gemm_bf16_d4(const GemmArgs& p, int epi, int act, hipStream_t st);
+bool gemm_bf16_s8_ok(const GemmArgs& p, int epi);                         // gemm_s8.hip
+int gemm_bf16_s8(const GemmArgs& p, int epi, int act, hipStream_t st);
 bool gemm_bf16_v8_ok(const GemmArgs& p, int epi);                         // gemm_v8.hip
 int gemm_bf16_v8(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,

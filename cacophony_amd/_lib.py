@@ -40,6 +40,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGNATURES = {
     "caco_version": (C.c_char_p, []),
     "caco_last_error": (C.c_char_p, []),
+    "caco_config_size": (_i32, []),
     "caco_default_config": (None, [C.POINTER(CacoConfigC)]),
     "caco_create": (C.c_int, [C.POINTER(CacoConfigC), C.POINTER(_vp)]),
     "caco_destroy": (None, [_vp]),
@@ -50,10 +51,14 @@ _SIGNATURES = {
     "caco_mel_num_frames": (_i64, [_i64]),
     "caco_mel_spectrogram": (C.c_int, [_vp, _i32, _i64, _f32, _f32, _vp, _vp]),
     "caco_mel_patches": (C.c_int, [_vp, _i32, _i64, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "caco_mel_patches_lens": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "caco_audio_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "caco_text_forward": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "caco_encode_audio": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "caco_encode_audio_ex": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp]),
+    "caco_encode_text": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "caco_similarity": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _f32, _vp, _i32, _vp]),
+    "caco_similarity_ld": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "caco_l2_normalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "caco_topk": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i32, _vp, _vp, _vp]),
     "caco_token_group_mean": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -61,6 +66,7 @@ _SIGNATURES = {
     "caco_workspace_bytes": (_i64, [_vp]),
     "caco_set_gemm_tile": (_i32, [_i32]),
     "caco_set_ln_fold": (_i32, [_i32]),
+    "caco_model_set_ln_fold": (_i32, [_vp, _i32]),
     "caco_profile_enable": (C.c_int, [_i32]),
     "caco_profile_report": (_i64, [C.c_char_p, _i64]),
     "caco_op_gemm_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
@@ -68,7 +74,6 @@ _SIGNATURES = {
     "caco_op_gemm_bf16_f32out": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "caco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "caco_op_attention": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "caco_set_attention64": (C.c_int, [_i32]),
     "caco_op_attention_qkv": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "caco_decode_begin": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "caco_decode_step": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -103,6 +108,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # caco_default_config memsets sizeof(caco_config) bytes: a stale struct on either side would overflow
+    if lib.caco_config_size() != C.sizeof(CacoConfigC):
+        raise RuntimeError(f"caco_config is {lib.caco_config_size()} bytes in {LIB_PATH} but {C.sizeof(CacoConfigC)} in this binding")
     _lib = lib
     return lib
 

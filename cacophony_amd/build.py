@@ -17,16 +17,14 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcaco_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w4.hip", "gemm_d4.hip", "gemm_s8.hip", "gemm_v8.hip", "attention.hip", "attention64.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w8.hip", "gemm_s8.hip", "attention.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "gemm_w8_epilogue.h", os.path.join(INCLUDE, "caco_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=fast"]
 
 
-# per-source extra flags.  attention64.hip: MFMA results that the VALU consumes (the scores) must live in architectural
-# VGPRs; with the default accumulation-register form the compiler copies every score through v_accvgpr_read.
-EXTRA_FLAGS = {"attention64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {}      # per-source extra hipcc flags
 
 
 def _hipcc() -> str:

@@ -8,7 +8,9 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -31,11 +33,41 @@ int check_hip(hipError_t e, const char* what) {
   return CACO_ERR_HIP;
 }
 
+// per (kernel, device): dynamic-LDS attribute set once; per device: CU count (kernels.h)
+int prepare_launch(const void* kern, int dyn_lds_bytes, int* num_cu) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> attr_done;
+  static int cus[CACO_MAX_DEVICES] = {};
+  int dev = 0;
+  CACO_HIP(hipGetDevice(&dev));
+  CACO_REQUIRE(dev >= 0 && dev < CACO_MAX_DEVICES, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (dyn_lds_bytes > 0) {
+    bool& done = attr_done[std::make_pair(kern, dev)];
+    if (!done) {
+      CACO_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_lds_bytes));
+      done = true;
+    }
+  }
+  if (num_cu) {
+    if (!cus[dev]) {
+      hipDeviceProp_t prop;
+      CACO_HIP(hipGetDeviceProperties(&prop, dev));
+      cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    *num_cu = cus[dev];
+  }
+  return CACO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
-// optional per-stage timing: HIP event pairs recorded on the caller's stream around each launch group
+// optional per-stage timing: HIP event pairs recorded on the caller's stream around each launch group.
+// Process-global by design (one report for everything that ran while it was on); the record list is guarded by a
+// mutex so that forwards on several host threads may run while it is enabled.
 // ------------------------------------------------------------------------------------------------
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static bool g_prof_on = false;
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 
@@ -46,11 +78,17 @@ static hipEvent_t prof_event() {
   return e;
 }
 struct ProfScope {
-  hipStream_t st; bool on;
+  hipStream_t st; bool on; hipEvent_t b = nullptr;
   ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof_on) {
-    if (on) { ProfRec r{name, prof_event(), prof_event()}; (void)hipEventRecord(r.a, st); g_prof_recs.push_back(r); }
+    if (on) {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      ProfRec r{name, prof_event(), prof_event()};
+      b = r.b;
+      (void)hipEventRecord(r.a, st);
+      g_prof_recs.push_back(r);
+    }
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(g_prof_recs.back().b, st); }
+  ~ProfScope() { if (on) (void)hipEventRecord(b, st); }
 };
 #define CACO_STAGE(name, expr)            \
   do {                                    \
@@ -109,6 +147,8 @@ using namespace caco;
 
 struct caco_model {
   caco_config cfg;
+  int device = 0;                    // the device the model was created on; every entry point checks it is current
+  int ln_fold = 0;                   // LayerNorm folding mode of the audio stack (caco_model_set_ln_fold)
   bool finalized = false;
   std::map<std::string, HostTensor> pending;
   std::vector<void*> owned;          // every device allocation holding weights
@@ -470,7 +510,7 @@ struct AudioWs {
 // (same box, interleaved): folding removes 2.2 ms of LayerNorm passes per step but the richer GEMM epilogues (bf16
 // copy + row statistics on out-proj / fc2, per-row correction on QKV / fc1) cost 2.7 ms, because a 256x256 tile's
 // epilogue runs with the matrix pipe idle.  Kept as an option (and tested) until the epilogue overlaps the K-loop.
-static int g_ln_fold = getenv("CACO_LN_FOLD") ? atoi(getenv("CACO_LN_FOLD")) : 0;
+static int g_ln_fold = getenv("CACO_LN_FOLD") ? atoi(getenv("CACO_LN_FOLD")) : 0;      // default of NEW models
 
 int linear_fold(const LinFold& L, const bf16_t* xb, const float* mr, int64_t M, int act, bf16_t* out, hipStream_t st, int ldc = 0) {
   GemmArgs g{xb, L.lin.w, L.lin.b, nullptr, out, M, L.lin.out, L.lin.in, ldc ? ldc : L.lin.out};
@@ -503,7 +543,7 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   float* part = A.at<float>(w.part);
   float* mr = A.at<float>(w.mr);
   const bool can_fold = !layers.empty() && layers[0].qkv_f.c1 != nullptr && H <= 1024;
-  const bool fold = can_fold && (g_ln_fold == 1 || (g_ln_fold < 0 && ((M + 255) / 256) * (H / 128) >= 4 * 256));
+  const bool fold = can_fold && (m->ln_fold == 1 || (m->ln_fold < 0 && ((M + 255) / 256) * (H / 128) >= 4 * 256));
   if (fold) {
     bf16_t* xb = h;                 // the bf16 operand buffer holds the RAW rows in this form
     CACO_STAGE("audio.ln", row_stats_bf16(x, M, H, eps, xb, mr, st));       // once per stack, at its entry
@@ -530,8 +570,21 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   return CACO_OK;
 }
 
+// The model's weights, arenas and per-device kernel state live on ONE device: a call with another device current would
+// dereference foreign memory.  Reject it instead.
+int check_device(const caco_model* m) {
+  int dev = -1;
+  CACO_HIP(hipGetDevice(&dev));
+  if (dev != m->device) {
+    set_error("model lives on device %d but device %d is current (hipSetDevice / torch.cuda.device first)", m->device, dev);
+    return CACO_ERR_STATE;
+  }
+  return CACO_OK;
+}
+
 int check_audio_shapes(const caco_model* m, int batch, int seq) {
   CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_TRY(check_device(m));
   CACO_REQUIRE(m->cfg.has_audio, "model was created without the audio tower");
   CACO_REQUIRE(batch > 0 && seq > 0, "bad audio shape B=%d S=%d", batch, seq);
   const int hd = m->cfg.audio_hidden / m->cfg.audio_heads;
@@ -559,7 +612,8 @@ int patches_as_bf16(const void* patches, int dtype, int64_t n, bf16_t* scratch, 
 // ================================================================================================
 extern "C" {
 
-const char* caco_version(void) { return "cacophony_amd 0.1 (gfx950)"; }
+const char* caco_version(void) { return "cacophony_amd 0.2 (gfx950)"; }
+int32_t caco_config_size(void) { return (int32_t)sizeof(caco_config); }
 const char* caco_last_error(void) { return caco::g_err; }
 
 void caco_default_config(caco_config* c) {
@@ -596,6 +650,8 @@ int caco_create(const caco_config* cfg, caco_model** out) {
   caco_model* m = new (std::nothrow) caco_model();
   CACO_REQUIRE(m, "caco_create: out of host memory");
   m->cfg = *cfg;
+  m->device = dev;
+  m->ln_fold = g_ln_fold;
   m->logit_scale = cfg->logit_scale;
   *out = m;
   return CACO_OK;
@@ -660,6 +716,11 @@ int32_t caco_set_ln_fold(int32_t mode) {
   if (mode >= -1 && mode <= 1) g_ln_fold = mode;
   return g_ln_fold;
 }
+int32_t caco_model_set_ln_fold(caco_model* m, int32_t mode) {
+  if (!m) return 0;
+  if (mode >= -1 && mode <= 1) m->ln_fold = mode;
+  return m->ln_fold;
+}
 
 int caco_profile_enable(int32_t on) {
   g_prof_on = on != 0;
@@ -667,6 +728,7 @@ int caco_profile_enable(int32_t on) {
 }
 
 int64_t caco_profile_report(char* buf, int64_t buflen) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   std::map<std::string, std::pair<double, long>> acc;
   for (ProfRec& r : g_prof_recs) {
     float ms = 0.f;
@@ -703,17 +765,26 @@ int caco_mel_spectrogram(const float* wav, int32_t batch, int64_t n_samples, flo
   return mel_frontend(wav, batch, n_samples, 0, scale, bias, mel, MEL_NATURAL_F32, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
-int caco_mel_patches(const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float scale, float bias,
-                     void* patches, int32_t dtype, float* tinds, float* finds, float* mask, void* stream) {
+int caco_mel_patches_lens(const float* wav, const int64_t* lengths, int32_t batch, int64_t n_samples, int32_t max_patches,
+                          float scale, float bias, void* patches, int32_t dtype, float* tinds, float* finds, float* mask,
+                          void* stream) {
   CACO_REQUIRE(dtype == CACO_DTYPE_F32 || dtype == CACO_DTYPE_BF16, "caco_mel_patches: patch dtype %d unknown", dtype);
   return mel_frontend(wav, batch, n_samples, max_patches, scale, bias, patches,
-                      dtype == CACO_DTYPE_BF16 ? MEL_PATCH_BF16 : MEL_PATCH_F32, tinds, finds, mask, (hipStream_t)stream);
+                      dtype == CACO_DTYPE_BF16 ? MEL_PATCH_BF16 : MEL_PATCH_F32, tinds, finds, mask, (hipStream_t)stream, lengths);
+}
+int caco_mel_patches(const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float scale, float bias,
+                     void* patches, int32_t dtype, float* tinds, float* finds, float* mask, void* stream) {
+  return caco_mel_patches_lens(wav, nullptr, batch, n_samples, max_patches, scale, bias, patches, dtype, tinds, finds, mask, stream);
 }
 
-int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const float* tinds, const float* finds,
-                       const float* mask, int32_t batch, int32_t seq, int32_t normalize, float* emb, float* hidden,
-                       void* stream) {
+}  // extern "C"
+
+// emb rows are written with stride ld_emb (0 = projection_size): both towers can fill one packed [B, 2, P] send buffer
+static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype, const float* tinds, const float* finds,
+                              const float* mask, int32_t batch, int32_t seq, int32_t normalize, float* emb, int32_t ld_emb,
+                              float* hidden, void* stream) {
   CACO_TRY(check_audio_shapes(m, batch, seq));
+  CACO_REQUIRE(ld_emb == 0 || (normalize && ld_emb >= m->cfg.projection_size), "audio forward: an embedding row stride needs normalize = 1 and ld >= projection_size");
   CACO_REQUIRE(patches && tinds && finds && mask && emb, "caco_audio_forward: null argument");
   CACO_REQUIRE(m->pool_wq, "caco_audio_forward: model has no audio pooler (AudioMAE-only weights)");
   hipStream_t st = (hipStream_t)stream;
@@ -749,13 +820,15 @@ int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const 
                                       pv + hh * phd, batch, phd, H, H, 1.0f, st, c.pool_heads * H));
   float* e = normalize ? A.at<float>(o_emb) : emb;
   CACO_STAGE("audio.proj_norm", gemm_f32(pv, m->pool_out_w, m->pool_out_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
-  if (normalize) CACO_STAGE("audio.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
+  if (normalize) CACO_STAGE("audio.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st, ld_emb));
   return CACO_OK;
 }
 
-int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, const int64_t* pos_ids, int32_t batch,
-                      int32_t seq, int32_t normalize, float* emb, float* hidden, void* stream) {
+static int text_forward_impl(caco_model* m, const int64_t* ids, const int64_t* mask, const int64_t* pos_ids, int32_t batch,
+                             int32_t seq, int32_t normalize, float* emb, int32_t ld_emb, float* hidden, void* stream) {
   CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_TRY(check_device(m));
+  CACO_REQUIRE(ld_emb == 0 || (normalize && ld_emb >= m->cfg.projection_size), "text forward: an embedding row stride needs normalize = 1 and ld >= projection_size");
   CACO_REQUIRE(m->cfg.has_text, "model was created without the text tower");
   CACO_REQUIRE(ids && mask && emb && batch > 0 && seq > 0, "caco_text_forward: bad arguments");
   const caco_config& c = m->cfg;
@@ -802,8 +875,24 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
   CACO_STAGE("text.pool", gemm_f32(pooled, m->tpool_v_w, m->tpool_v_b, pv, batch, H, H, H, 1.0f, st));
   float* e = normalize ? A.at<float>(o_emb) : emb;
   CACO_STAGE("text.proj_norm", gemm_f32(pv, m->text_proj_w, m->text_proj_b, e, batch, c.projection_size, H, c.projection_size, 1.0f, st));
-  if (normalize) CACO_STAGE("text.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st));
+  if (normalize) CACO_STAGE("text.proj_norm", l2_normalize(e, batch, c.projection_size, emb, st, ld_emb));
   return CACO_OK;
+}
+
+extern "C" {
+
+int caco_audio_forward(caco_model* m, const void* patches, int32_t dtype, const float* tinds, const float* finds,
+                       const float* mask, int32_t batch, int32_t seq, int32_t normalize, float* emb, float* hidden,
+                       void* stream) {
+  return audio_forward_impl(m, patches, dtype, tinds, finds, mask, batch, seq, normalize, emb, 0, hidden, stream);
+}
+int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, const int64_t* pos_ids, int32_t batch,
+                      int32_t seq, int32_t normalize, float* emb, float* hidden, void* stream) {
+  return text_forward_impl(m, ids, mask, pos_ids, batch, seq, normalize, emb, 0, hidden, stream);
+}
+int caco_encode_text(caco_model* m, const int64_t* ids, const int64_t* mask, int32_t batch, int32_t seq, float* emb,
+                     int32_t ld_emb, void* stream) {
+  return text_forward_impl(m, ids, mask, nullptr, batch, seq, 1, emb, ld_emb, nullptr, stream);
 }
 
 // RobertaDecoder.forward (roberta.py:337-373) as called by CACO.get_decoder_logits (caco.py:212-240): teacher-forced
@@ -811,6 +900,7 @@ int caco_text_forward(caco_model* m, const int64_t* ids, const int64_t* mask, co
 int caco_decoder_forward(caco_model* m, const float* text_hidden, const int64_t* text_mask, const float* audio_hidden,
                          const float* audio_mask, int32_t batch, int32_t seq_t, int32_t seq_a, float* logits, void* stream) {
   CACO_REQUIRE(m && m->finalized, "model is null or weights not finalized");
+  CACO_TRY(check_device(m));
   CACO_REQUIRE(!m->dlayers.empty() && m->dec_proj.w, "Decoder module not initialized");
   CACO_REQUIRE(text_hidden && text_mask && audio_hidden && audio_mask && logits && batch > 0 && seq_t > 0 && seq_a > 0,
                "caco_decoder_forward: bad arguments");
@@ -889,6 +979,7 @@ void caco_decode_end(caco_decode_state* s) {
 int caco_decode_begin(caco_model* m, const float* audio_hidden, const float* audio_mask, int32_t batch, int32_t seq_audio,
                       int32_t max_len, caco_decode_state** out, void* stream) {
   CACO_REQUIRE(m && m->finalized && out, "caco_decode_begin: bad arguments");
+  CACO_TRY(check_device(m));
   CACO_REQUIRE(!m->dlayers.empty() && m->dec_proj.w, "Decoder module not initialized");
   CACO_REQUIRE(audio_hidden && audio_mask && batch > 0 && seq_audio > 0 && max_len > 0, "caco_decode_begin: bad arguments");
   CACO_REQUIRE(max_len <= m->cfg.text_max_pos, "caco_decode_begin: max_len %d exceeds max_position_embeddings %d", max_len, m->cfg.text_max_pos);
@@ -939,6 +1030,7 @@ int caco_decode_begin(caco_model* m, const float* audio_hidden, const float* aud
 // decoder's distribution over the NEXT token.
 int caco_decode_step(caco_decode_state* s, const int64_t* token_ids, float* logits, void* stream) {
   CACO_REQUIRE(s && s->m && token_ids && logits, "caco_decode_step: bad arguments");
+  CACO_TRY(check_device(s->m));
   CACO_REQUIRE(s->pos < s->max_len, "caco_decode_step: position %d reached max_len %d", s->pos, s->max_len);
   caco_model* m = s->m;
   hipStream_t st = (hipStream_t)stream;
@@ -992,10 +1084,14 @@ int caco_decode_step(caco_decode_state* s, const int64_t* token_ids, float* logi
   return CACO_OK;
 }
 
-int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float* emb,
-                      void* stream) {
+int caco_encode_audio_ex(caco_model* m, const float* wav, const int64_t* lengths, int32_t batch, int64_t n_samples,
+                         int32_t max_patches, float* emb, int32_t ld_emb, void* stream) {
   CACO_TRY(check_audio_shapes(m, batch, max_patches));
   CACO_REQUIRE(wav && emb && n_samples > 0, "caco_encode_audio: bad arguments");
+  // the fused front end emits 16 x 16 patches of a 128-bin mel spectrogram: 256 values per patch, 8 frequency patches
+  CACO_REQUIRE(m->cfg.patch_size == 256 && m->cfg.num_freq_patches == 8,
+               "caco_encode_audio: the fused front end needs patch_size 256 / num_freq_patches 8 (model has %d / %d)",
+               m->cfg.patch_size, m->cfg.num_freq_patches);
   hipStream_t st = (hipStream_t)stream;
   // front-end outputs live in their own arena so that the forward's arena growth cannot move them
   const size_t n_tok = (size_t)batch * max_patches;
@@ -1006,10 +1102,21 @@ int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_
   float* tinds = F.at<float>(o_i);
   float* finds = tinds + n_tok;
   float* mask = finds + n_tok;
-  CACO_STAGE("mel.patches", mel_frontend(wav, batch, n_samples, max_patches, 0.2f, 0.9f, patches, MEL_PATCH_BF16, tinds, finds, mask, st));
-  return caco_audio_forward(m, patches, CACO_DTYPE_BF16, tinds, finds, mask, batch, max_patches, 1, emb, nullptr, stream);
+  CACO_STAGE("mel.patches", mel_frontend(wav, batch, n_samples, max_patches, 0.2f, 0.9f, patches, MEL_PATCH_BF16, tinds, finds, mask, st, lengths));
+  return audio_forward_impl(m, patches, CACO_DTYPE_BF16, tinds, finds, mask, batch, max_patches, 1, emb, ld_emb, nullptr, stream);
+}
+int caco_encode_audio(caco_model* m, const float* wav, int32_t batch, int64_t n_samples, int32_t max_patches, float* emb,
+                      void* stream) {
+  return caco_encode_audio_ex(m, wav, nullptr, batch, n_samples, max_patches, emb, 0, stream);
 }
 
+int caco_similarity_ld(const float* a, int32_t na, int32_t lda, const float* t, int32_t nt, int32_t ldt, int32_t dim, float scale,
+                       float* out, int32_t ld_out, void* stream) {
+  CACO_REQUIRE(a && t && out, "caco_similarity: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  CACO_STAGE("similarity", gemm_f32(a, t, nullptr, out, na, nt, dim, ld_out, scale, st, lda, ldt));
+  return CACO_OK;
+}
 int caco_similarity(const float* a, int32_t na, const float* t, int32_t nt, int32_t dim, float scale, float* out,
                     int32_t ld_out, void* stream) {
   CACO_REQUIRE(a && t && out, "caco_similarity: null argument");
@@ -1097,7 +1204,6 @@ int caco_op_layernorm(const float* x, const float* g, const float* b, int64_t ro
                       void* ob, void* stream) {
   return layernorm(x, g, b, rows, dim, eps, of, (bf16_t*)ob, (hipStream_t)stream);
 }
-int caco_set_attention64(int32_t on) { return set_attention64(on); }
 
 int caco_op_attention_qkv(const void* q, int32_t q_ld, int32_t seq_q, const void* kv, int32_t ld, int32_t k_off, int32_t v_off,
                           const float* mask, int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal,

@@ -310,16 +310,6 @@ __global__ __launch_bounds__(NW * 64, ATTN_OCC) void attention_kernel(const bf16
 
 }  // namespace
 
-static int g_attn64 = -1;
-int attention64_enabled() {
-  if (g_attn64 < 0) g_attn64 = (getenv("CACO_ATTN64") && atoi(getenv("CACO_ATTN64"))) ? 1 : 0;
-  return g_attn64;
-}
-int set_attention64(int on) {
-  g_attn64 = on ? 1 : 0;
-  return g_attn64;
-}
-
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st) {
   return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0);
@@ -335,14 +325,6 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);
   CACO_REQUIRE(!causal || seq_q == seq, "attention: the causal mask needs seq_q == seq (%d vs %d)", seq_q, seq);
   CACO_REQUIRE(q_ld % 8 == 0, "attention: query row stride must be a multiple of 8 elements");
-  CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
-  CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
-  CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
-  {   // Opt-in experiment (CACO_ATTN64=1): the two-pass 64-rows-per-wave kernel of attention64.hip for non-causal shapes.
-      // Same results (same tests), measured 10 % SLOWER than this kernel at the encoder shape (460 vs 415 us) and 20 % at
-      // S = 1500: see the header of attention64.hip and DESIGN.md 4.2 for the cycle anatomy.
-    if (attention64_enabled() && !causal && seq_q >= 128 && kv_batch_rows == seq) return attention64(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, out, st);
-  }
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");

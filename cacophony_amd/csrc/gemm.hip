@@ -168,210 +168,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs p) {
   epilogue_direct<TM, TN, EPI, ACT>(acc, p, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 256x256 tile, persistent, phased K-loop with counted waits
-// ------------------------------------------------------------------------------------------------
-constexpr int HALF_BYTES = 128 * ROW_BYTES;   // 16 KiB half-tile: 128 rows x 64 bf16
-constexpr int TILE_BYTES = 4 * HALF_BYTES;    // B0 B1 A0 A1
-constexpr int P8_SMEM = 2 * TILE_BYTES;       // 128 KiB
-// during an epilogue the next tile's first six half-tiles are landing in buffer 0 and buffer 1's B halves;
-// buffer 1's A halves (32 KiB) are idle and serve as the eight per-wave transpose slabs
-constexpr int P8_SCRATCH_OFF = TILE_BYTES + 2 * HALF_BYTES;
-static_assert(8 * EPI_SCRATCH_BYTES <= 2 * HALF_BYTES, "epilogue slabs must fit in the idle A halves");
-
-// Stream element s = 4 * kt + h of one output tile, h: 0 = B0, 1 = B1, 2 = A0, 3 = A1 (B first: its buffers die first).
-__device__ __forceinline__ void p8_stage(const GemmArgs& p, int s, int nk, int64_t m0, int n0, int lda, int ldw,
-                                         char* smem, int wave, int lane) {
-  const int kt = s >> 2, h = s & 3;
-  if (kt >= nk) return;
-  char* dst = smem + (kt & 1) * TILE_BYTES + h * HALF_BYTES;
-  if (h < 2)
-    stage_tile<128, 8>(p.W, n0 + h * 128, p.N - 1, ldw, kt * BK, dst, wave, lane);
-  else
-    stage_tile<128, 8>(p.A, m0 + (h - 2) * 128, p.M - 1, lda, kt * BK, dst, wave, lane);
-}
-
-// One phase = READ segment (fragment reads + one half-tile of loads + waits) | barrier | 16 MFMAs | barrier.
-#define P8_MFMA_SEGMENT(ACC_I0, ACC_J0, BF)                                                      \
-  __builtin_amdgcn_s_barrier();                                                                 \
-  __builtin_amdgcn_s_setprio(1);                                                                \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                              \
-    acc[ACC_I0 + i][ACC_J0 + jj] = mma(af[i][kk], BF[jj][kk], acc[ACC_I0 + i][ACC_J0 + jj]); \
-  __builtin_amdgcn_s_setprio(0);                                                                \
-  __builtin_amdgcn_s_barrier();
-
-template <int EPI, int ACT>
-__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(GemmArgs p, int skew) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
-
-  const int tiles_n = p.N / 256;
-  const int tiles_m = (int)((p.M + 255) / 256);
-  const int nwg = tiles_m * tiles_n;
-  // XCD x owns the contiguous logical tiles [base, base + cnt); its gridDim/8 workgroups deal them round-robin
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int cnt = q + (xcd < r ? 1 : 0);
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  int li = slot;
-  if (li >= cnt) return;
-  const int nk = p.K / BK;
-
-  // De-synchronise the CUs: identical tiles would otherwise march in lock step and hit HBM with every
-  // workgroup's epilogue stores at the same instant.  Each quarter of the workgroups starts a little later.
-  for (int d = (slot & 3) * skew; d > 0; --d) __builtin_amdgcn_s_sleep(127);
-
-  const int frow = lane & 15, fchunk = lane >> 4;
-  // this wave's operand windows inside a tile buffer: A half wm (all 128 rows), B half wn>>1 (64 of its rows)
-  const int a_off = (2 + wm) * HALF_BYTES;
-  const int b_off = (wn >> 1) * HALF_BYTES + (wn & 1) * 64 * ROW_BYTES;
-  char* sc = smem + P8_SCRATCH_OFF + wave * EPI_SCRATCH_BYTES;
-
-  int t = base + li;
-  int64_t m0 = (int64_t)(t / tiles_n) * 256;
-  int n0 = (t % tiles_n) * 256;
-  // prologue: K-tile 0 complete + the B halves of K-tile 1
-#pragma unroll
-  for (int s = 0; s < 6; ++s) p8_stage(p, s, nk, m0, n0, lda, ldw, smem, wave, lane);
-
-  while (true) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K-tile 0 must have landed in every wave's share before the first read (also retires the previous tile's stores)
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // Stagger: wave row 1 runs one barrier slot behind wave row 0.  Every SIMD hosts one wave of each row, so
-    // while one of them issues its 16 MFMAs the other does its LDS reads / load issue, and they swap each slot.
-    if (wm == 1) __builtin_amdgcn_s_barrier();
-
-    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-    for (int j = 0; j < nk; ++j) {
-      const char* buf = smem + (j & 1) * TILE_BYTES;
-      const char* a_t = buf + a_off;
-      const char* b_t = buf + b_off;
-      const int s0 = 4 * j + 6;
-      // ---- phase 1: quadrant (m0, n0): read B.n0 and A.m0 ---------------------------------------------
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) b0f[jj][kk] = lds_frag(b_t, jj * 16 + frow, kk * 4 + fchunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_frag(a_t, i * 16 + frow, kk * 4 + fchunk);
-      p8_stage(p, s0, nk, m0, n0, lda, ldw, smem, wave, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      P8_MFMA_SEGMENT(0, 0, b0f)
-      // ---- phase 2: quadrant (m0, n1): read B.n1 ------------------------------------------------------
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) b1f[jj][kk] = lds_frag(b_t, 32 + jj * 16 + frow, kk * 4 + fchunk);
-      p8_stage(p, s0 + 1, nk, m0, n0, lda, ldw, smem, wave, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      P8_MFMA_SEGMENT(0, 2, b1f)
-      // ---- phase 3: quadrant (m1, n1): read A.m1; K-tile j's B halves are dead from here ----------------
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) af[i][kk] = lds_frag(a_t, 64 + i * 16 + frow, kk * 4 + fchunk);
-      p8_stage(p, s0 + 2, nk, m0, n0, lda, ldw, smem, wave, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      P8_MFMA_SEGMENT(4, 2, b1f)
-      // ---- phase 4: quadrant (m1, n0): B.n0 is still in registers; retire K-tile j+1 --------------------
-      p8_stage(p, s0 + 3, nk, m0, n0, lda, ldw, smem, wave, lane);
-      if (j + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the two newest half-tiles may stay in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      P8_MFMA_SEGMENT(4, 0, b0f)
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the stagger: every wave executes the same barrier count
-    // every wave has finished reading LDS: start the next tile's loads, then store this tile under them
-    const int64_t m_cur = m0;
-    const int n_cur = n0;
-    li += slots;
-    const bool more = li < cnt;
-    if (more) {
-      t = base + li;
-      m0 = (int64_t)(t / tiles_n) * 256;
-      n0 = (t % tiles_n) * 256;
-#pragma unroll
-      for (int s = 0; s < 6; ++s) p8_stage(p, s, nk, m0, n0, lda, ldw, smem, wave, lane);
-    }
-    wave_epilogue_128x64<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 64, lane, sc);
-    if (!more) break;
-  }
-}
-
 template <int BM, int BN, int WM, int WN, int EPI, int ACT>
 int launch_cfg(const GemmArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
   auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, ACT>;
-  static bool attr_done = false;   // per instantiation; benign race (idempotent)
-  if (!attr_done) {
-    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), smem, nullptr));
   const int tiles = (int)((p.M + BM - 1) / BM) * (p.N / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, st, p);
   return check_hip(hipGetLastError(), "gemm_bf16 launch");
 }
 
 template <int EPI, int ACT>
-int launch_p8(const GemmArgs& p, hipStream_t st) {
-  auto kern = gemm_bf16_p8_kernel<EPI, ACT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM));
-    attr_done = true;
-  }
-  const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CACO_HIP(hipGetDevice(&dev));
-    CACO_HIP(hipGetDeviceProperties(&prop, dev));
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  static int skew = getenv("CACO_P8_SKEW") ? atoi(getenv("CACO_P8_SKEW")) : 1;
-  const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;     // one resident workgroup per CU (128 KiB LDS)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), P8_SMEM, st, p, tiles > grid ? skew : 0);
-  return check_hip(hipGetLastError(), "gemm_bf16_p8 launch");
-}
-
-template <int EPI, int ACT>
 int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   const int cfg = gemm_tile_config();
   const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
-  const bool p8_ok = p.N % 256 == 0 && p.K >= 2 * BK;
   if (p.fold_mr || p.xb_out || p.stats_part) {      // LayerNorm folding lives in the 8-wave kernel's epilogue only
-    CACO_REQUIRE(gemm_bf16_w4_ok(p, epi), "gemm_bf16: LayerNorm folding needs N %% 256 == 0 and K %% 64 == 0");
-    return gemm_bf16_w4(p, epi, act, 8, st);
+    CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16: LayerNorm folding needs N %% 256 == 0 and K %% 64 == 0");
+    return gemm_bf16_w8(p, epi, act, st);
   }
-  if (cfg == 1256 && p8_ok) return launch_p8<EPI, ACT>(p, st);
-  if (cfg == 9256 && gemm_bf16_v8_ok(p, epi)) return gemm_bf16_v8(p, epi, act, st);
-  if ((cfg == 4256 || cfg == 8256) && gemm_bf16_w4_ok(p, epi)) return gemm_bf16_w4(p, epi, act, cfg == 8256 ? 8 : 4, st);
-  if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
-  if (cfg == 5256 && gemm_bf16_d4_ok(p, epi)) return gemm_bf16_d4(p, epi, act, st);
+  // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 6256 = w8 with the epilogue under its own K-loop
+  // (gemm_s8.hip: measured a draw), 2256 = 256x128 two workgroups per CU
+  if (cfg == 8256 && gemm_bf16_w8_ok(p, epi)) return gemm_bf16_w8(p, epi, act, st);
   if (cfg == 6256 && gemm_bf16_s8_ok(p, epi)) return gemm_bf16_s8(p, epi, act, st);
+  if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
   if (cfg == 256) {
-    // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w4.hip; most reuse per L2 byte, measured
-    // 2-10 % faster than the phased kernel below on the encoder shapes) when every CU gets >= 2 tiles,
-    // else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128
-    // threshold in 256x128-tile units.  128 also sends the text tower's M = 8192 GEMMs here: in isolation the 128x128
+    // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w4.hip: most reuse per L2 byte) when every
+    // CU gets >= 2 tiles, else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128.
+    // Threshold in 256x128-tile units.  128 also sends the text tower's M = 8192 GEMMs to w8: in isolation the 128x128
     // kernel is faster for its N = 768 shapes, but the text tower runs NEXT TO the audio tower and a few persistent
     // 160 KiB workgroups interleave with the audio GEMMs better than many small ones (step 32.2 -> 31.7 ms measured)
     static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
-    if (gemm_bf16_w4_ok(p, epi) && tiles_x >= w8_min) return gemm_bf16_w4(p, epi, act, 8, st);
+    if (gemm_bf16_w8_ok(p, epi) && tiles_x >= w8_min) return gemm_bf16_w8(p, epi, act, st);
     if (tiles_x >= 256) return gemm_bf16_x(p, epi, act, st);
   }
   return launch_cfg<128, 128, 2, 2, EPI, ACT>(p, st);
@@ -388,7 +215,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 1256 || tile == 2256 || tile == 4256 || tile == 8256 || tile == 9256 || tile == 5256 || tile == 6256) g_tile_cfg = tile;   // 1256 / 2256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256 || tile == 6256) g_tile_cfg = tile;   // > 256: force a kernel
   return gemm_tile_config();
 }
 
@@ -419,7 +246,7 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st) {
 namespace {
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        const float* __restrict__ bias, float* __restrict__ C, int M,
-                                                       int N, int K, int ldc, float scale, int lda) {
+                                                       int N, int K, int ldc, float scale, int lda, int ldb) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int tiles_n = (N + 31) / 32;
@@ -430,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int rb = min(tn * 32 + (lane & 31), N - 1);
   const int half = lane >> 5;
   const float* ap = A + (int64_t)ra * lda + half * 4;
-  const float* bp = B + (int64_t)rb * K + half * 4;
+  const float* bp = B + (int64_t)rb * ldb + half * 4;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -452,12 +279,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }  // namespace
 
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
-             hipStream_t st, int lda) {
+             hipStream_t st, int lda, int ldb) {
   CACO_REQUIRE(M > 0 && N > 0 && K > 0 && (K % 8 == 0), "gemm_f32: need M,N > 0 and K %% 8 == 0 (got %d,%d,%d)", M, N, K);
   CACO_REQUIRE(ldc >= N, "gemm_f32: ldc %d < N %d", ldc, N);
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
   CACO_REQUIRE(lda == 0 || (lda >= K && lda % 4 == 0), "gemm_f32: lda %d must be >= K and a multiple of 4", lda);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, A, B, bias, C, M, N, K, ldc, scale, lda ? lda : K);
+  CACO_REQUIRE(ldb == 0 || (ldb >= K && ldb % 4 == 0), "gemm_f32: ldb %d must be >= K and a multiple of 4", ldb);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3((tiles + 3) / 4), dim3(256), 0, st, A, B, bias, C, M, N, K, ldc, scale, lda ? lda : K, ldb ? ldb : K);
   return check_hip(hipGetLastError(), "gemm_f32 launch");
 }
 

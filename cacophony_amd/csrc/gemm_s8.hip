@@ -357,21 +357,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int ACT>
 int launch_s8(const GemmArgs& p, hipStream_t st) {
   void (*kern)(GemmArgs) = gemm_bf16_s8_kernel<ACT>;
-  int dev = 0;
-  CACO_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) dev = 0;
-  static bool attr_done[16] = {};
-  static int num_cu[16] = {};
-  if (!attr_done[dev]) {
-    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S_SMEM));
-    attr_done[dev] = true;
-  }
-  if (!num_cu[dev]) {
-    hipDeviceProp_t prop;
-    CACO_HIP(hipGetDeviceProperties(&prop, dev));
-    num_cu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  const int grid = num_cu[dev] / 8 * 8;
+  int num_cu = 0;
+  CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), S_SMEM, &num_cu));
+  const int grid = num_cu / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), S_SMEM, st, p);
   return check_hip(hipGetLastError(), "gemm_bf16_s8 launch");
 }

@@ -1,32 +1,32 @@
-// gemm_bf16_w4: 256x256x64 bf16 MFMA GEMM, FOUR waves per workgroup = one wave per SIMD, persistent.
+// gemm_bf16_w8: 256x256x64 bf16 MFMA GEMM, EIGHT waves per workgroup (2 (M) x 4 (N), wave tile 128 x 64 = two waves per
+// SIMD), one persistent workgroup per CU.  The default kernel for chip-filling shapes.
 //   out[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
-//
-// Why this shape (DESIGN.md "GEMM"): with a single wave per SIMD nothing competes for the SIMD's matrix pipe, so the
-// K-loop is one in-order stream per SIMD in which LDS fragment reads, DMA issue and scalar work ride in the issue
-// slots between back-to-back MFMAs (32 cycles each).  Every wave owns a 128x128 output tile (4x4 MFMA blocks,
-// 256 fp32 accumulators per lane in the AGPR half of the unified 512-entry register file): the largest per-wave
-// tile, hence the fewest LDS bytes per MFMA (32 KiB of fragments per 64 MFMAs), the fewest L2 bytes per FLOP
-// (128 FLOP/B) and ONE barrier per 64-deep K-tile.
 //
 //   LDS (160 KiB = the whole CU)   A ring: 3 slots x 32 KiB (256 rows x 128 B), W ring: 2 slots x 32 KiB.
 //             The activation operand streams from HBM and is prefetched TWO K-tiles ahead; the weight operand is
 //             L2-resident and is prefetched one K-tile ahead.  The slot of the K-tile just consumed doubles as the
-//             epilogue's transpose slab (8 KiB per wave).
-//   loads     buffer_load_dwordx4 ... lds (16-byte DMA, no VGPR round trip), spread over the K-tile (one piece per
-//             4 MFMAs), retired by ONE counted s_waitcnt vmcnt(8) per K-tile: never 0 in the loop, loads stay in
-//             flight across the barrier and across output-tile boundaries (the next tile's first K-tiles land while
-//             this tile's epilogue runs)
+//             epilogue's transpose slab (4 KiB per wave).
+//   loads     buffer_load_dwordx4 ... lds (16-byte DMA, no VGPR round trip), spread over the K-tile, retired by ONE counted
+//             s_waitcnt vmcnt(4) per K-tile: never 0 in the loop, loads stay in flight across the barrier and across
+//             output-tile boundaries (the next tile's first K-tiles land while this tile's epilogue runs)
 //   LDS image lane-linear (DMA constraint); the bank swizzle (16-byte chunk c ^ ((row >> 1) & 7)) is applied to the
 //             per-lane SOURCE offset and undone on the ds_read_b128 side
-//   K-loop    rotated: body(g) = ks0 ks1 ks2 | vmcnt(8) lgkmcnt(0) s_barrier | ks3.  Fragments are double-buffered in
-//             registers one 16-deep step ahead (also across K-tiles and output tiles); the MFMA order inside a step
-//             uses the fragments in the order they were read, so every ds_read has >= 11 MFMA slots to land.
+//   K-loop    rotated: body(g) = ks0 ks1 ks2 | vmcnt(4) lgkmcnt(0) s_barrier | ks3.  Fragments are double-buffered in
+//             registers one 16-deep step ahead (also across K-tiles and output tiles).  Per wave and 16-deep step: 8 MFMAs,
+//             6 fragment reads; per K-tile 4 A pieces (ks1, ks2) + 4 W pieces (ks3).  A wave that is stalled (DMA issue,
+//             fragment wait, barrier) leaves the SIMD's matrix pipe to its partner; nothing forces their phase.
 //   MFMA      operands swapped (weights = A operand) so that a lane owns 4 CONSECUTIVE n of one output row m
-//   epilogue  bias / SiLU / erf-GELU / residual in registers; 32-row slabs transposed through the wave's XOR-swizzled
-//             LDS slab so that every global access is a whole 256-byte row segment; residual rows are fetched a slab
-//             ahead
+//   epilogue  gemm_w8_epilogue.h: bias / SiLU / erf-GELU / residual / LayerNorm-fold forms in registers; 32-row slabs
+//             transposed through the wave's XOR-swizzled LDS slab so that every global access is a whole 128-byte row
+//             segment; residual rows are fetched a slab ahead
 //   schedule  persistent; XCD x owns a contiguous run of tiles (n fastest), so the tiles that share an A row panel
 //             run together on one XCD's L2
+//
+// Round-2 anatomy (tools/w8_timing.py): per 256x256 tile at K = 768 the K-loop takes ~28 k cycles (MFMA
+// pipe 88 % busy), the epilogue 9.7 k (bf16) .. 11.6 k (SiLU) .. 44 k (fp32 + residual) with the matrix pipe idle; the
+// epilogue is bound by the CU's own issue / store path, not by HBM.  Ablation builds: -DW4_NOEPI, -DW8_NOMFMA, -DW8_A2,
+// -DW8_TIMING (tools/build_variant.sh).  Retired siblings (4-wave 128x128-per-wave form, phased p8, two-accumulator v8,
+// two-workgroups-per-CU d4): git history / tools/experimental/.
 //
 // Reference ops replaced: nn.Linear + activation + residual add (audio_models/mae.py:55-61,69-74,92-97,133;
 // text_models/roberta.py:62-64,110,153,164; caco.py:35-37).
@@ -43,7 +43,6 @@ constexpr int W_SLOT = 256 * WROWB;           // 32 KiB: one operand's K-tile
 constexpr int W_AOFF = 0;                     // A ring: slots 0..2
 constexpr int W_WOFF = 3 * W_SLOT;            // W ring: slots 0..1
 constexpr int W_SMEM = 5 * W_SLOT;            // 163840 = 160 KiB
-constexpr int W_SLAB = 8192;                  // per-wave epilogue slab inside a dead A slot
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
@@ -63,7 +62,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 
 // Tile order.  The n-tiles are processed in groups of G (p.ngroup): all M panels of one group, then the next group,
 // n fastest inside a group.  A group's weight rows (G x 256 x K bf16) then stay in the XCD's 4 MiB L2 for the whole
-// pass instead of being re-streamed through it once per M panel.  Off by default (launch_w4).
+// pass instead of being re-streamed through it once per M panel.  Off by default (launch_w8).
 __device__ __forceinline__ void w4_decode(int t, int tiles_n, int tiles_m, int G, int& tm, int& tn) {
   const int per = tiles_m * G;
   const int g = t / per;                 // groups before the last one are full
@@ -134,242 +133,6 @@ __device__ __forceinline__ bf16x8 w4_frag(const char* oper, int row, int chunk) 
   return *reinterpret_cast<const bf16x8*>(oper + row * WROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// MFMA order inside a 16-deep step.  Fragments are read x0 w0 x1 w1 x2 w2 x3 w3; this order touches them as late as
-// their read position allows, so the last-read fragment is first needed by the 13th MFMA of the step.
-__device__ constexpr int W4_ORD_I[16] = {0, 1, 0, 1, 2, 2, 0, 1, 2, 3, 3, 3, 0, 1, 2, 3};
-__device__ constexpr int W4_ORD_J[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 3, 3};
-
-// One 16-deep step: 16 MFMAs on the CURRENT fragment set while the NEXT set is read (8 ds_read_b128) and up to four
-// DMA pieces are issued.  Reads and DMA pieces alternate in SOURCE order (the scheduler keeps LDS reads and LDS-DMA
-// writes in program order); the group barriers then spread them: one read per two MFMAs, one DMA piece per four.
-#define W4_STEP(XN, WN, XA, WW, KS, XC, WC, DMA_STMT)                                             \
-  _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_) {                                             \
-    if (W4_DO_READS) {                                                                           \
-      if (n_ & 1) WN[n_ >> 1] = w4_frag(WW, (n_ >> 1) * 32 + frow, (KS) * 2 + fhalf);            \
-      else XN[n_ >> 1] = w4_frag(XA, (n_ >> 1) * 32 + frow, (KS) * 2 + fhalf);                   \
-    }                                                                                            \
-    if (n_ & 1) { const int q_ = n_ >> 1; DMA_STMT; }                                            \
-  }                                                                                              \
-  _Pragma("unroll") for (int o_ = 0; o_ < 16; ++o_) {                                            \
-    const int i_ = W4_ORD_I[o_], j_ = W4_ORD_J[o_];                                              \
-    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[j_], XC[i_], acc[i_][j_], 0, 0, 0); \
-  }                                                                                              \
-  _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_) {                                             \
-    __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 2, 0);                                     \
-    __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                                     \
-    if (n_ & 1) __builtin_amdgcn_sched_group_barrier(W4_SGB_VMEM, 1, 0);                         \
-  }                                                                                              \
-  __builtin_amdgcn_sched_barrier(0);
-
-template <int EPI, int ACT>
-__device__ __forceinline__ void w4_epilogue(const f32x16 (&acc)[4][4], const GemmArgs& p, int64_t mw, int nw, int lane, char* slab) {
-  const int lm = lane & 31, lh = lane >> 5;
-  const int rrow = lane >> 4, c16 = lane & 15;          // read-back: 4 rows x 256 B per instruction
-  if constexpr (EPI == EPI_BF16) {
-    // per 32-row block row: 32 x 128 bf16 slab, 256-byte pitch, 16-byte chunk c of row r at c ^ (r & 15)
-    f32x4 b4[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        b4[j][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + nw + c16 * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)w4_epi_act<ACT>(acc[i][j][g * 4 + r] + b4[j][g][r]);
-          *reinterpret_cast<bf16x4*>(slab + lm * 256 + (((j * 4 + g) ^ (lm & 15)) << 4) + lh * 8) = o;
-        }
-#pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int row = tt * 4 + rrow;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(slab + row * 256 + ((c16 ^ (row & 15)) << 4));
-        const int64_t m = mw + i * 32 + row;
-        if (m < p.M) *reinterpret_cast<bf16x8*>(outp + m * p.ldc) = v;
-      }
-    }
-  } else {   // EPI_F32: eight 32 x 64 fp32 slabs (256-byte pitch); the residual of slab s+1 is fetched while slab s is processed
-    f32x4 res[2][8];
-    auto fetch = [&](int s, f32x4 (&dst)[8]) {
-      const int i = s >> 1, jh = s & 1;
-#pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int64_t m = min(mw + i * 32 + tt * 4 + rrow, p.M - 1);
-        dst[tt] = *reinterpret_cast<const f32x4*>(p.resid + m * p.ldc + nw + jh * 64 + c16 * 4);
-      }
-    };
-    if (p.resid) fetch(0, res[0]);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = s >> 1, jh = s & 1;
-      if (p.resid && s + 1 < 8) fetch(s + 1, res[(s + 1) & 1]);
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int j = jh * 2 + jj;
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
-          *reinterpret_cast<f32x4*>(slab + lm * 256 + (((jj * 8 + g * 2 + lh) ^ (lm & 15)) << 4)) = v;
-        }
-#pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int row = tt * 4 + rrow;
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((c16 ^ (row & 15)) << 4));
-        const int64_t m = mw + i * 32 + row;
-        if (p.resid) v += res[s & 1][tt];
-        if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * p.ldc + nw + jh * 64 + c16 * 4) = v;
-      }
-    }
-  }
-}
-
-template <int EPI, int ACT>
-__device__ __forceinline__ void w4_body(const GemmArgs& p, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
-
-  const int tiles_n = p.N / 256;
-  const int tiles_m = (int)((p.M + 255) / 256);
-  const int nwg = tiles_m * tiles_n;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int cnt = q + (xcd < r ? 1 : 0);
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  if (slot >= cnt) return;
-  const int nk = p.K / WBK;
-
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int x_off = wm * 128 * WROWB, w_off = wn * 128 * WROWB;
-
-  // Past the last K-tile a cursor keeps re-reading its last tile (valid memory, into slots nobody reads any more):
-  // the K-loop then has no branch around its DMA instructions and every step stays one basic block.
-  W4CurA<4> CA;
-  W4CurW CW;
-  CA.li = CW.li = slot;
-  CA.kt = CW.kt = 0;
-  w4_setup_a(CA, p, base + slot, tiles_n, lda, wave, lane);
-  w4_setup_w(CW, p, base + slot, tiles_n, ldw, wave, lane);
-  auto advance_a = [&]() {
-    if (++CA.kt == nk) {
-      CA.kt = 0;
-      if (CA.li + slots < cnt) { CA.li += slots; w4_setup_a(CA, p, base + CA.li, tiles_n, lda, wave, lane); }
-    }
-  };
-  auto advance_w = [&]() {
-    if (++CW.kt == nk) {
-      CW.kt = 0;
-      if (CW.li + slots < cnt) { CW.li += slots; w4_setup_w(CW, p, base + CW.li, tiles_n, ldw, wave, lane); }
-    }
-  };
-
-  // ring state: byte offsets of the slots of K-tiles g, g+1, g+2 (A) and g, g+1 (W)
-  int a_c = W_AOFF, a_1 = W_AOFF + W_SLOT, a_2 = W_AOFF + 2 * W_SLOT;
-  int w_c = W_WOFF, w_1 = W_WOFF + W_SLOT;
-
-  // prologue: A(0) W(0) | A(1) W(1)[0..3]
-#pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_c, wave);
-  advance_a();
-#pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
-  advance_w();
-#pragma unroll
-  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_1, wave);
-  advance_a();
-#pragma unroll
-  for (int it = 0; it < 4; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_1, wave);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  bf16x8 x0[4], w0[4], x1[4], w1[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    x0[i] = w4_frag(smem + a_c + x_off, i * 32 + frow, fhalf);
-    w0[i] = w4_frag(smem + w_c + w_off, i * 32 + frow, fhalf);
-  }
-
-  int c_li = slot;
-  while (true) {
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* xa = smem + a_c + x_off;
-      const char* ww = smem + w_c + w_off;
-      // ks0: compute (g,0), read (g,1); W(g+1) pieces 4..7
-      W4_STEP(x1, w1, xa, ww, 1, x0, w0, w4_piece_w<4>(CW, 4 + q_, ldw, smem + w_1, wave))
-      advance_w();
-      // ks1: compute (g,1), read (g,2); A(g+2) pieces 0..3
-      W4_STEP(x0, w0, xa, ww, 2, x1, w1, w4_piece_a<4>(CA, q_, smem + a_2, wave))
-      // ks2: compute (g,2), read (g,3); A(g+2) pieces 4..7
-      W4_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a<4>(CA, 4 + q_, smem + a_2, wave))
-      advance_a();
-      // A(g+1) and W(g+1) have landed (only A(g+2) may still be in flight); every wave is done reading A(g), W(g)
-#ifdef W4_NOLGKM
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef W4_NOBARRIER
-      __builtin_amdgcn_s_barrier();
-#endif
-#ifdef W4_SKEW
-      // de-phase the four waves by one MFMA slot each so that their DMA instructions do not hit the CU's single
-      // texture-address path in the same cycle
-      if (wave & 1) { _Pragma("unroll") for (int z = 0; z < W4_SKEW; ++z) asm volatile("s_nop 15"); }
-      if (wave & 2) { _Pragma("unroll") for (int z = 0; z < 2 * W4_SKEW; ++z) asm volatile("s_nop 15"); }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      // ks3: compute (g,3), read (g+1,0) (possibly of the next output tile); W(g+2) pieces 0..3 -> slot of W(g)
-      W4_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w<4>(CW, q_, ldw, smem + w_c, wave))
-      // rotate the rings
-      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
-      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
-    }
-    const int t = base + c_li;
-    int tm_, tn_;
-    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
-    const int64_t m_cur = (int64_t)tm_ * 256;
-    const int n_cur = tn_ * 256;
-#ifdef W4_NOEPI
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-#else
-    // the slot of the K-tile just consumed (now a_2) is dead until A(g+3) is issued into it in the next ks1
-    w4_epilogue<EPI, ACT>(acc, p, m_cur + wm * 128, n_cur + wn * 128, lane, smem + a_2 + wave * W_SLAB);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
-#endif
-    c_li += slots;
-    if (c_li >= cnt) break;
-  }
-}
-
-
-// ================================================================================================
-// Eight-wave form: the same tile, rings, rotated K-loop and counted waits, but 2 (M) x 4 (N) waves of 128 x 64 each
-// = TWO waves per SIMD.  A wave that is stalled issuing an LDS-DMA instruction (~60 cycles each, measured), waiting
-// for a fragment or at the barrier leaves the SIMD's matrix pipe to its partner, which runs the same stream a
-// little out of phase; nothing forces the phase (no per-phase barriers).
-//   per wave and 16-deep step: 8 MFMAs, 6 fragment reads (x0 w0 x1 w1 x2 x3)
-//   per wave and K-tile: 4 A pieces (ks1, ks2) + 4 W pieces (ks3); s_waitcnt vmcnt(4) leaves A(g+2) in flight at the barrier
-// ================================================================================================
 #ifdef W8_NOMFMA      // ablation: the K-loop's memory side alone (DMA + fragment reads + barriers), no matrix instructions
 #define W8_MFMAS(XC, WC)                                                                         \
   _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) asm volatile("" ::"v"(XC[q_]));               \
@@ -610,36 +373,17 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   }
 }
 
-template <int EPI, int ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  w4_body<EPI, ACT>(p, smem);
-}
-
 template <int EPI, int ACT, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_w8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   w8_body<EPI, ACT, MODE>(p, smem);
 }
 
-template <int EPI, int ACT, int NWV, int MODE = 0>
-int launch_w4(const GemmArgs& p, hipStream_t st) {
-  void (*kern)(GemmArgs) = nullptr;
-  if constexpr (NWV == 8) kern = gemm_bf16_w8_kernel<EPI, ACT, MODE>;
-  else kern = gemm_bf16_w4_kernel<EPI, ACT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM));
-    attr_done = true;
-  }
-  static int num_cu = 0;
-  if (!num_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    CACO_HIP(hipGetDevice(&dev));
-    CACO_HIP(hipGetDeviceProperties(&prop, dev));
-    num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+template <int EPI, int ACT, int MODE = 0>
+int launch_w8(const GemmArgs& p, hipStream_t st) {
+  void (*kern)(GemmArgs) = gemm_bf16_w8_kernel<EPI, ACT, MODE>;
+  int num_cu = 0;
+  CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), W_SMEM, &num_cu));
   const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
   static const int env_grid = getenv("CACO_W8_MAXGRID") ? atoi(getenv("CACO_W8_MAXGRID")) : 0;     // experiments: fewer CUs
   const int cus = env_grid > 0 && env_grid < num_cu ? env_grid : num_cu;
@@ -650,56 +394,52 @@ int launch_w4(const GemmArgs& p, hipStream_t st) {
     static const int env_g = getenv("CACO_W_NGROUP") ? atoi(getenv("CACO_W_NGROUP")) : 0;
     const int tiles_n = p.N / 256;
     q.ngroup = (env_g > 0 && env_g < tiles_n) ? env_g : tiles_n;
+    // start-time spread of the workgroups (units of 1024 cycles): measured without effect (0 .. 128), the epilogue is not
+    // HBM-bound; kept as an experiment switch
     static const int env_s = getenv("CACO_W8_STAGGER") ? atoi(getenv("CACO_W8_STAGGER")) : 0;
-    q.stagger = (NWV == 8 && tiles > grid) ? env_s : 0;
+    q.stagger = tiles > grid ? env_s : 0;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), W_SMEM, st, q);
-  return check_hip(hipGetLastError(), "gemm_bf16_w4 launch");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), W_SMEM, st, q);
+  return check_hip(hipGetLastError(), "gemm_bf16_w8 launch");
 }
 
 }  // namespace
 
-bool gemm_bf16_w4_ok(const GemmArgs& p, int epi) {
+bool gemm_bf16_w8_ok(const GemmArgs& p, int epi) {
   return p.N % 256 == 0 && p.K % WBK == 0 && p.K >= WBK &&
          (int64_t)256 * (p.lda ? p.lda : p.K) * 2 < 0x7fffffff && (int64_t)256 * (p.ldw ? p.ldw : p.K) * 2 < 0x7fffffff;
 }
 
-template <int NWV>
-static int gemm_bf16_w_t(const GemmArgs& p, int epi, int act, hipStream_t st) {
-  CACO_REQUIRE(gemm_bf16_w4_ok(p, epi), "gemm_bf16_w4: shape not supported");
-  if constexpr (NWV == 8) {   // the specialised epilogues (w8_epilogue): bias only, bias + residual
-    static const bool generic = getenv("CACO_W8_GENERIC") && atoi(getenv("CACO_W8_GENERIC"));
-    const bool plain = !generic && p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
-    if (plain && epi == EPI_BF16 && !p.resid) {
-      if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, 8, 1>(p, st);
-      if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, 8, 1>(p, st);
-      if (act == ACT_GELU) return launch_w4<EPI_BF16, ACT_GELU, 8, 1>(p, st);
-    }
-    if (plain && epi == EPI_F32 && act == ACT_NONE) {
-      if (p.resid) return launch_w4<EPI_F32, ACT_NONE, 8, 2>(p, st);
-      return launch_w4<EPI_F32, ACT_NONE, 8, 1>(p, st);
-    }
-    // LayerNorm-folded stack (api.hip run_audio_layers): consumer = bias + fold, producer = bias + residual + bf16 copy + sums
-    if (!generic && p.bias && p.fold_mr && !p.resid && !p.xb_out && !p.stats_part && epi == EPI_BF16) {
-      if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, 8, 3>(p, st);
-      if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, 8, 3>(p, st);
-    }
-    if (!generic && p.bias && p.resid && p.xb_out && p.stats_part && !p.fold_mr && epi == EPI_F32 && act == ACT_NONE)
-      return launch_w4<EPI_F32, ACT_NONE, 8, 4>(p, st);
+int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
+  CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16_w8: shape not supported");
+  // compile-time specialised epilogues (w8_epilogue MODE): 1 bias only, 2 bias + residual, 3 bias + LayerNorm-fold consumer,
+  // 4 bias + residual + fold producer (bf16 copy + row sums); 0 = generic (everything tested at run time)
+  static const bool generic = getenv("CACO_W8_GENERIC") && atoi(getenv("CACO_W8_GENERIC"));
+  const bool plain = !generic && p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
+  if (plain && epi == EPI_BF16 && !p.resid) {
+    if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE, 1>(p, st);
+    if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU, 1>(p, st);
+    if (act == ACT_GELU) return launch_w8<EPI_BF16, ACT_GELU, 1>(p, st);
   }
+  if (plain && epi == EPI_F32 && act == ACT_NONE) {
+    if (p.resid) return launch_w8<EPI_F32, ACT_NONE, 2>(p, st);
+    return launch_w8<EPI_F32, ACT_NONE, 1>(p, st);
+  }
+  if (!generic && p.bias && p.fold_mr && !p.resid && !p.xb_out && !p.stats_part && epi == EPI_BF16) {
+    if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE, 3>(p, st);
+    if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU, 3>(p, st);
+  }
+  if (!generic && p.bias && p.resid && p.xb_out && p.stats_part && !p.fold_mr && epi == EPI_F32 && act == ACT_NONE)
+    return launch_w8<EPI_F32, ACT_NONE, 4>(p, st);
   if (epi == EPI_BF16) {
-    if (act == ACT_NONE) return launch_w4<EPI_BF16, ACT_NONE, NWV>(p, st);
-    if (act == ACT_SILU) return launch_w4<EPI_BF16, ACT_SILU, NWV>(p, st);
-    if (act == ACT_GELU) return launch_w4<EPI_BF16, ACT_GELU, NWV>(p, st);
+    if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE>(p, st);
+    if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU>(p, st);
+    if (act == ACT_GELU) return launch_w8<EPI_BF16, ACT_GELU>(p, st);
   } else if (epi == EPI_F32 && act == ACT_NONE) {
-    return launch_w4<EPI_F32, ACT_NONE, NWV>(p, st);
+    return launch_w8<EPI_F32, ACT_NONE>(p, st);
   }
-  set_error("gemm_bf16_w4: unsupported epilogue %d / activation %d", epi, act);
+  set_error("gemm_bf16_w8: unsupported epilogue %d / activation %d", epi, act);
   return CACO_ERR_INVALID;
-}
-
-int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st) {
-  return waves == 8 ? gemm_bf16_w_t<8>(p, epi, act, st) : gemm_bf16_w_t<4>(p, epi, act, st);
 }
 
 }  // namespace caco

@@ -125,11 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_x_kernel(GemmArgs p) {
 template <int EPI, int ACT>
 int launch_x(const GemmArgs& p, hipStream_t st) {
   auto kern = gemm_bf16_x_kernel<EPI, ACT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, XSMEM));
-    attr_done = true;
-  }
+  CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), XSMEM, nullptr));
   const int tiles = (int)((p.M + XBM - 1) / XBM) * (p.N / XBN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), XSMEM, st, p);
   return check_hip(hipGetLastError(), "gemm_bf16_x launch");

@@ -29,25 +29,33 @@ struct GemmArgs {
   float* stats_part;      // [M, N/64] (sum, sum of squares) pairs over each wave's 64 columns, or null
 };
 
+// Per-device launch preparation shared by every kernel that needs more than 64 KiB of dynamic LDS or sizes its grid by the
+// CU count: sets hipFuncAttributeMaxDynamicSharedMemorySize for `kern` on the CURRENT device (once per kernel and device) and
+// returns that device's CU count.  (Round 1 kept this in function-local statics: a second model on another GPU would have
+// launched without the attribute and with the first device's CU count.)
+constexpr int CACO_MAX_DEVICES = 16;
+int prepare_launch(const void* kern, int dyn_lds_bytes, int* num_cu);      // api.hip
+#define CACO_TRY_RC(expr)    \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc) return _rc;     \
+  } while (0)
+
 int gemm_tile_config();
 int set_gemm_tile_config(int tile);
 int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
-bool gemm_bf16_w4_ok(const GemmArgs& p, int epi);                         // gemm_w4.hip
-int gemm_bf16_w4(const GemmArgs& p, int epi, int act, int waves, hipStream_t st);   // waves: 4 or 8
-bool gemm_bf16_d4_ok(const GemmArgs& p, int epi);                         // gemm_d4.hip
-int gemm_bf16_d4(const GemmArgs& p, int epi, int act, hipStream_t st);
-bool gemm_bf16_s8_ok(const GemmArgs& p, int epi);                         // gemm_s8.hip
+bool gemm_bf16_w8_ok(const GemmArgs& p, int epi);                         // gemm_w8.hip: persistent 256x256, the default
+int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st);
+bool gemm_bf16_s8_ok(const GemmArgs& p, int epi);                         // gemm_s8.hip: w8 with the epilogue under its K-loop
 int gemm_bf16_s8(const GemmArgs& p, int epi, int act, hipStream_t st);
-bool gemm_bf16_v8_ok(const GemmArgs& p, int epi);                         // gemm_v8.hip
-int gemm_bf16_v8(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
-             hipStream_t st, int lda = 0);     // lda: row stride of A in elements (0 = K)
+             hipStream_t st, int lda = 0, int ldb = 0);     // lda / ldb: row strides of A / B in elements (0 = K)
 
 // norm.hip
 int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
               bf16_t* out_bf16, hipStream_t st);
-int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st);
+int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st, int ld_out = 0);   // ld_out: row stride of out (0 = dim)
 int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                   const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
                   float eps, float* out_f32, bf16_t* out_bf16, hipStream_t st, int pos_base = 0);   // position = row % seq + pos_base
@@ -70,12 +78,6 @@ int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
                   int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows = 0);
 
-int attention64_enabled();
-int set_attention64(int on);
-// attention64.hip: non-causal form with 64 query rows per wave, one wave per SIMD
-int attention64(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
-                int batch, int seq, int heads, int head_dim, bf16_t* out, hipStream_t st);
-
 // pool.hip: learned-query attention pooling over the encoder output rows themselves (projections folded out):
 // x bf16 [B, S, H], wq fp32 [heads, H] -> out fp32 [B, heads, H]
 int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,
@@ -87,8 +89,9 @@ int topk_rows(const float* sim, int rows, int cols, int64_t row_stride, int64_t 
               hipStream_t st);
 
 // mel.hip
+// lengths: int64 [batch] valid samples per clip (device), or null = every clip is n_samples long
 int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias,
-                 void* out, int mode, float* tinds, float* finds, float* mask, hipStream_t st);
+                 void* out, int mode, float* tinds, float* finds, float* mask, hipStream_t st, const int64_t* lengths = nullptr);
 enum { MEL_NATURAL_F32 = 0, MEL_PATCH_F32 = 1, MEL_PATCH_BF16 = 2 };
 
 }  // namespace caco

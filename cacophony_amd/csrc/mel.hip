@@ -243,15 +243,26 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
 }
 
 // zero rows [valid, S) of the patch tensor and write time / freq indices and mask
-// (spectrogram_to_patches, eval_caco_torch.py:132-144)
+// (spectrogram_to_patches, eval_caco_torch.py:132-144).  lengths != null: clip b holds lengths[b] real samples (the rest of
+// its row is zero padding): its spectrogram has ceil(len / 160) frames and only the patches of those frames are valid -
+// what the reference gets by running prepare_audio_batch (:181-206) clip by clip.  The mel values of the frames it does
+// have are the same either way: the STFT pads with zeros (:78).
 template <typename T>
 __global__ void patch_meta_kernel(T* __restrict__ patches, float* __restrict__ tinds, float* __restrict__ finds,
-                                  float* __restrict__ mask, int S, int valid, int nfreq) {
+                                  float* __restrict__ mask, int S, int valid, int nfreq, const int64_t* __restrict__ lengths,
+                                  int64_t n_samples) {
   const int b = blockIdx.y;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= S) return;
   const int lane = threadIdx.x & 63;
-  const bool keep = p < valid;
+  int valid_b = valid;
+  if (lengths) {
+    int64_t len = lengths[b];
+    len = len < 0 ? 0 : (len > n_samples ? n_samples : len);
+    const int64_t full_b = ((len + HOP - 1) / HOP / FPB) * nfreq;
+    valid_b = full_b < valid ? (int)full_b : valid;
+  }
+  const bool keep = p < valid_b;
   if (lane == 0) {
     const int q = keep ? p : 0;
     if (tinds) tinds[(int64_t)b * S + p] = (float)(q / nfreq);
@@ -264,10 +275,13 @@ __global__ void patch_meta_kernel(T* __restrict__ patches, float* __restrict__ t
   }
 }
 
-MelTables* g_tables = nullptr;   // device copy, created once per process (single device per process)
+MelTables* g_tables_dev[CACO_MAX_DEVICES] = {};   // device copies, one per device, created at first use
 
-int ensure_tables() {
-  if (g_tables) return CACO_OK;
+int ensure_tables(MelTables** out) {
+  int dev = 0;
+  CACO_HIP(hipGetDevice(&dev));
+  CACO_REQUIRE(dev >= 0 && dev < CACO_MAX_DEVICES, "mel: device index %d out of range", dev);
+  if (g_tables_dev[dev]) { *out = g_tables_dev[dev]; return CACO_OK; }
   std::vector<char> hostbuf(sizeof(MelTables), 0);
   MelTables* h = reinterpret_cast<MelTables*>(hostbuf.data());
   const double PI = 3.14159265358979323846;
@@ -313,7 +327,8 @@ int ensure_tables() {
   MelTables* d = nullptr;
   CACO_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(MelTables)));
   CACO_HIP(hipMemcpy(d, h, sizeof(MelTables), hipMemcpyHostToDevice));
-  g_tables = d;
+  g_tables_dev[dev] = d;
+  *out = d;
   return CACO_OK;
 }
 
@@ -327,10 +342,11 @@ int mel_grid_x(int nblk, int batch) {
 }  // namespace
 
 int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches, float scale, float bias, void* out,
-                 int mode, float* tinds, float* finds, float* mask, hipStream_t st) {
+                 int mode, float* tinds, float* finds, float* mask, hipStream_t st, const int64_t* lengths) {
   CACO_REQUIRE(wav && out && batch > 0 && n_samples > 0, "mel: bad arguments (batch %d, n_samples %lld)", batch, (long long)n_samples);
   CACO_REQUIRE(batch <= 65535, "mel: batch %d exceeds the grid limit", batch);
-  int rc = ensure_tables();
+  MelTables* g_tables = nullptr;
+  int rc = ensure_tables(&g_tables);
   if (rc) return rc;
   const int frames = (int)((n_samples + HOP - 1) / HOP);
   if (mode == MEL_NATURAL_F32) {
@@ -356,14 +372,14 @@ int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches
     rc = check_hip(hipGetLastError(), "mel patch launch");
     if (rc) return rc;
   }
-  if (valid < max_patches || tinds || finds || mask) {
+  if (valid < max_patches || tinds || finds || mask || lengths) {
     const dim3 grid((max_patches + 3) / 4, batch);
     if (mode == MEL_PATCH_BF16)
       hipLaunchKernelGGL(patch_meta_kernel<bf16_t>, grid, dim3(256), 0, st, reinterpret_cast<bf16_t*>(out), tinds, finds,
-                         mask, max_patches, valid, nfreq);
+                         mask, max_patches, valid, nfreq, lengths, n_samples);
     else
       hipLaunchKernelGGL(patch_meta_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<float*>(out), tinds, finds, mask,
-                         max_patches, valid, nfreq);
+                         max_patches, valid, nfreq, lengths, n_samples);
     rc = check_hip(hipGetLastError(), "patch meta launch");
   }
   return rc;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const int64_t* __res
 }
 
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int rows, int dim,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int ld_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restri
     s += y * y;
   }
   const float inv = 1.0f / sqrtf(wave_sum(s));
-  for (int i = lane; i < dim; i += 64) out[(int64_t)row * dim + i] = x[(int64_t)row * dim + i] * inv;
+  for (int i = lane; i < dim; i += 64) out[(int64_t)row * ld_out + i] = x[(int64_t)row * dim + i] * inv;
 }
 
 // x[m, n] = (base ? base[n] : x[m, n]) + sincos(time[m])[n] + freq_table[freq[m]][n]
@@ -261,9 +261,9 @@ int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word,
   return check_hip(hipGetLastError(), "text_embed_ln launch");
 }
 
-int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st) {
-  CACO_REQUIRE(rows > 0 && dim > 0 && x && out, "l2_normalize: bad arguments");
-  hipLaunchKernelGGL(l2_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, out);
+int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st, int ld_out) {
+  CACO_REQUIRE(rows > 0 && dim > 0 && x && out && (ld_out == 0 || ld_out >= dim), "l2_normalize: bad arguments");
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, out, ld_out ? ld_out : dim);
   return check_hip(hipGetLastError(), "l2_normalize launch");
 }
 

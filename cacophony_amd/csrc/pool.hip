@@ -154,12 +154,10 @@ int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batc
   const size_t smem = (size_t)PW * heads * (hidden + 2) * sizeof(float);
   CACO_REQUIRE(smem <= 160 * 1024, "attn_pool: hidden %d too large for the LDS combine buffer", hidden);
   if (heads == 1) {
-    static bool attr1 = false;
-    if (!attr1) { CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr1 = true; }
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<1>), 160 * 1024, nullptr));
     hipLaunchKernelGGL(pool_rows_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
   } else {
-    static bool attr2 = false;
-    if (!attr2) { CACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr2 = true; }
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<2>), 160 * 1024, nullptr));
     hipLaunchKernelGGL(pool_rows_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
   }
   return check_hip(hipGetLastError(), "attn_pool launch");

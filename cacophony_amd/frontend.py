@@ -82,8 +82,10 @@ def spectrogram_to_patches(spectrogram: np.ndarray, time_patch_size: int = 16, f
 
 
 def mel_patches_device(wav: torch.Tensor, max_patches: int, dtype: torch.dtype = torch.float32, scale: float = 0.2,
-                       bias: float = 0.9) -> Dict[str, torch.Tensor]:
-    """Fused waveform -> patch batch on the GPU: wav [B, n] -> the four tensors get_audio_embedding takes."""
+                       bias: float = 0.9, lengths=None) -> Dict[str, torch.Tensor]:
+    """Fused waveform -> patch batch on the GPU: wav [B, n] -> the four tensors get_audio_embedding takes.
+    `lengths` int64 [B]: real samples per clip when the rows are zero-padded clips of different lengths; clip b then gets
+    exactly the patches / indices / mask of prepare_audio_batch (eval_caco_torch.py:181-206) run on that clip alone."""
     lib = _lib.load()
     if dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("patch dtype must be float32 or bfloat16")
@@ -98,21 +100,35 @@ def mel_patches_device(wav: torch.Tensor, max_patches: int, dtype: torch.dtype =
     tinds = torch.empty(B, max_patches, dtype=torch.float32, device=dev)
     finds = torch.empty_like(tinds)
     mask = torch.empty_like(tinds)
+    lens = None
+    if lengths is not None:
+        lens = _dev_tensor(lengths, torch.int64, dev, "lengths")
+        if tuple(lens.shape) != (B,):
+            raise ValueError(f"lengths must be [{B}], got {tuple(lens.shape)}")
     with torch.cuda.device(dev):
-        _lib.check(lib.caco_mel_patches(_ptr(wav), B, n, max_patches, scale, bias, _ptr(patches),
-                                        _lib.DTYPE_BF16 if dtype == torch.bfloat16 else _lib.DTYPE_F32, _ptr(tinds),
-                                        _ptr(finds), _ptr(mask), _stream()), "mel_patches")
+        _lib.check(lib.caco_mel_patches_lens(_ptr(wav), _ptr(lens), B, n, max_patches, scale, bias, _ptr(patches),
+                                             _lib.DTYPE_BF16 if dtype == torch.bfloat16 else _lib.DTYPE_F32, _ptr(tinds),
+                                             _ptr(finds), _ptr(mask), _stream()), "mel_patches")
     return {"audio_patches": patches, "audio_time_inds": tinds, "audio_freq_inds": finds, "audio_mask": mask}
 
 
-def prepare_audio_batch(audio, datasetconfig: DatasetConfig, device=None) -> Dict[str, torch.Tensor]:
-    """src/eval/eval_caco_torch.py:181-206; also accepts a batch [B, n] (the reference takes one clip)."""
+def prepare_audio_batch(audio, datasetconfig: DatasetConfig, device=None, lengths=None) -> Dict[str, torch.Tensor]:
+    """src/eval/eval_caco_torch.py:181-206 (one clip -> batch of one).  Also accepts a batch [B, n], or a LIST of clips
+    of different lengths (padded here, each masked at its own length, as the reference does clip by clip); `lengths`
+    gives the real sample counts of an already padded [B, n] batch."""
     if datasetconfig.time_patch_size != 16 or datasetconfig.freq_patch_size != 16:
         raise ValueError("the HIP front end is specialised for 16 x 16 patches")
+    if isinstance(audio, (list, tuple)) and len(audio) > 0 and np.ndim(audio[0]) == 1:
+        clips = [c if torch.is_tensor(c) else torch.as_tensor(np.asarray(c)) for c in audio]
+        lengths = torch.tensor([int(c.numel()) for c in clips], dtype=torch.int64)
+        n = int(lengths.max())
+        audio = torch.zeros(len(clips), n, dtype=torch.float32)
+        for i, c in enumerate(clips):
+            audio[i, : c.numel()] = c.to(torch.float32).cpu()
     audio = audio if torch.is_tensor(audio) else torch.as_tensor(np.asarray(audio))
     if audio.dim() == 1:
         audio = audio[None]
-    return mel_patches_device(audio.to(_device(device), torch.float32), datasetconfig.patches_seq_len)
+    return mel_patches_device(audio.to(_device(device), torch.float32), datasetconfig.patches_seq_len, lengths=lengths)
 
 
 def prepare_text_batch(text: str, tokenizer, max_text_len: int, device=None) -> Dict[str, torch.Tensor]:

@@ -112,6 +112,11 @@ class _HipModel:
             raise RuntimeError("cacophony_amd models live on the GPU only")
         return self
 
+    def set_ln_fold(self, mode: int) -> int:
+        """LayerNorm folding of THIS model's audio stack: 0 = separate LayerNorm passes (default), 1 = folded into the
+        neighbouring GEMM epilogues, -1 = folded when the batch fills the chip.  Returns the mode in force."""
+        return int(self._lib.caco_model_set_ln_fold(self._handle, int(mode)))
+
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.caco_workspace_bytes(self._handle))
@@ -169,8 +174,20 @@ class CACO(_HipModel):
                        "get_audio_embedding")
         return (emb, hidden) if return_hidden_state else emb
 
+    def _check_token_ids(self, ids: Tensor, pos: Optional[Tensor]) -> None:
+        """nn.Embedding raises IndexError on an out-of-range id (roberta.py:44-47); the embedding kernel would clamp it
+        and return a plausible but wrong embedding.  One device reduction + host sync: callers on a hot path that
+        already trust their tokenizer pass check_ids=False."""
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= self.text_config.vocab_size:
+            raise IndexError(f"text_input_ids out of range [0, {self.text_config.vocab_size}): min {lo}, max {hi}")
+        if pos is not None:
+            lo, hi = int(pos.min()), int(pos.max())
+            if lo < 0 or hi >= self.text_config.max_position_embeddings:
+                raise IndexError(f"position_ids out of range [0, {self.text_config.max_position_embeddings}): min {lo}, max {hi}")
+
     def get_text_embedding(self, text_input_ids, text_mask, position_ids=None, deterministic: bool = True,
-                           return_hidden_state: bool = True, normalize: bool = False):
+                           return_hidden_state: bool = True, normalize: bool = False, check_ids: bool = True):
         """caco.py:152-177"""
         self._inference_only(deterministic)
         ids = _dev_tensor(text_input_ids, torch.int64, self.device, "text_input_ids")
@@ -183,6 +200,8 @@ class CACO(_HipModel):
             pos = _dev_tensor(position_ids, torch.int64, self.device, "position_ids")
             if pos.shape != ids.shape:
                 pos = pos.expand(B, T).contiguous()
+        if check_ids:
+            self._check_token_ids(ids, pos)
         emb = torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
         hidden = torch.empty(B, T, self.text_config.hidden_size, dtype=torch.float32, device=self.device) \
             if return_hidden_state else None
@@ -241,58 +260,97 @@ class CACO(_HipModel):
     __call__ = forward
 
     # ---- convenience wrappers named in BASELINE.json north_star ---------------------------------
-    def encode_audio(self, wav, max_patches: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    @staticmethod
+    def _out_rows(out: Optional[Tensor], B: int, P: int, device, what: str) -> Tuple[Tensor, int]:
+        """`out`: fp32 [B, P] whose rows may be strided (e.g. bank[:, 0, :] of a packed [B, 2, P] exchange buffer)."""
+        if out is None:
+            return torch.empty(B, P, dtype=torch.float32, device=device), 0
+        if tuple(out.shape) != (B, P) or out.dtype != torch.float32 or out.stride(1) != 1 or out.stride(0) < P or out.device != device:
+            raise ValueError(f"{what}: `out` must be fp32 [{B}, {P}] on {device} with unit column stride")
+        return out, int(out.stride(0))
+
+    def encode_audio(self, wav, max_patches: Optional[int] = None, out: Optional[Tensor] = None, lengths=None) -> Tensor:
         """wav fp32 [B, n_samples] (16 kHz) -> L2-normalised audio embeddings [B, projection_size].
-        = prepare_audio_batch (eval_caco_torch.py:181-206) + get_audio_embedding(normalize=True), all on device."""
+        = prepare_audio_batch (eval_caco_torch.py:181-206) + get_audio_embedding(normalize=True), all on device.
+        `lengths` int64 [B]: real samples per clip when the clips differ in length (rows zero-padded to n_samples); each
+        clip is then masked exactly as the reference masks it when it pre-processes that clip alone."""
         wav = _dev_tensor(wav, torch.float32, self.device, "wav")
         if wav.dim() == 1:
             wav = wav[None]
         B, n = wav.shape
         if max_patches is None:
             max_patches = max(8, n * 8 // 160 // 16)    # patches_seq_len rule, eval_caco_torch.py:573,607-612
-        emb = out if out is not None else torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
-        if tuple(emb.shape) != (B, self.caco_config.projection_size) or emb.dtype != torch.float32 or not emb.is_contiguous():
-            raise ValueError("encode_audio: `out` must be a contiguous fp32 [B, projection_size] tensor")
+        lens = None
+        if lengths is not None:
+            lens = _dev_tensor(lengths, torch.int64, self.device, "lengths")
+            if tuple(lens.shape) != (B,):
+                raise ValueError(f"lengths must be [{B}], got {tuple(lens.shape)}")
+        emb, ld = self._out_rows(out, B, self.caco_config.projection_size, self.device, "encode_audio")
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.caco_encode_audio(self._handle, _ptr(wav), B, n, int(max_patches), _ptr(emb), _stream()),
-                       "encode_audio")
+            _lib.check(self._lib.caco_encode_audio_ex(self._handle, _ptr(wav), _ptr(lens), B, n, int(max_patches), _ptr(emb), ld,
+                                                      _stream()), "encode_audio")
         return emb
 
-    def encode_text(self, text_input_ids, text_mask) -> Tensor:
-        return self.get_text_embedding(text_input_ids, text_mask, return_hidden_state=False, normalize=True)
+    def encode_text(self, text_input_ids, text_mask, out: Optional[Tensor] = None, check_ids: bool = True) -> Tensor:
+        """ids / mask int64 [B, T] -> L2-normalised text embeddings [B, projection_size] (get_text_embedding, normalize=True)."""
+        ids = _dev_tensor(text_input_ids, torch.int64, self.device, "text_input_ids")
+        mask = _dev_tensor(text_mask, torch.int64, self.device, "text_mask")
+        if ids.dim() != 2 or ids.shape != mask.shape:
+            raise ValueError(f"text_input_ids / text_mask must both be [B, T], got {tuple(ids.shape)} / {tuple(mask.shape)}")
+        if check_ids:
+            self._check_token_ids(ids, None)
+        B, T = ids.shape
+        emb, ld = self._out_rows(out, B, self.caco_config.projection_size, self.device, "encode_text")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.caco_encode_text(self._handle, _ptr(ids), _ptr(mask), B, T, _ptr(emb), ld, _stream()), "encode_text")
+        return emb
 
-    def encode_pairs(self, wav, text_input_ids, text_mask, max_patches: Optional[int] = None,
-                     audio_streams: int = 1) -> Tuple[Tensor, Tensor]:
+    def encode_pairs(self, wav, text_input_ids, text_mask, max_patches: Optional[int] = None, audio_streams: int = 1,
+                     lengths=None, packed: bool = False, check_ids: bool = False):
         """Embed clips and captions CONCURRENTLY: the text tower runs on a side stream next to the audio tower, and
         the clip batch is split over `audio_streams` streams.  The library keeps one workspace per (tower, stream),
         so the launches of different streams interleave on the GPU: one stream's memory-bound kernels (LayerNorm,
         attention, GEMM epilogues) fill the HBM time another stream's MFMA-bound GEMM leaves idle.  Same results
-        as encode_audio + encode_text.  Returns (audio_emb [B,P], text_emb [Bt,P]), valid on the current stream."""
+        as encode_audio + encode_text.  Returns (audio_emb [B,P], text_emb [B,P]), valid on the current stream;
+        packed=True: both towers write into ONE fp32 [B, 2, P] buffer (the all-gather payload of the data-parallel
+        path, dist.gather_packed) and that buffer is returned instead.  Token ids are not range-checked here unless
+        check_ids (a host sync per call): this is the throughput path."""
         wav = _dev_tensor(wav, torch.float32, self.device, "wav")
         if wav.dim() == 1:
             wav = wav[None]
         B = wav.shape[0]
+        Bt = int(text_input_ids.shape[0])
+        P = self.caco_config.projection_size
+        if packed and Bt != B:
+            raise ValueError(f"encode_pairs(packed=True) needs as many captions as clips, got {Bt} vs {B}")
+        lens = None if lengths is None else _dev_tensor(lengths, torch.int64, self.device, "lengths")
         n_split = max(1, min(int(audio_streams), B))
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
             pool = self._side_streams(n_split)            # n_split - 1 audio side streams + 1 text stream
-            ea = torch.empty(B, self.caco_config.projection_size, dtype=torch.float32, device=self.device)
+            if packed:
+                bank = torch.empty(B, 2, P, dtype=torch.float32, device=self.device)
+                ea, et = bank[:, 0, :], bank[:, 1, :]
+            else:
+                bank = None
+                ea = torch.empty(B, P, dtype=torch.float32, device=self.device)
+                et = torch.empty(Bt, P, dtype=torch.float32, device=self.device)
             bounds = [B * i // n_split for i in range(n_split + 1)]
             for st in pool:
                 st.wait_stream(cur)
             with torch.cuda.stream(pool[-1]):
-                et = self.encode_text(text_input_ids, text_mask)
-                et.record_stream(cur)
+                self.encode_text(text_input_ids, text_mask, out=et, check_ids=check_ids)
             for i in range(n_split):
                 lo, hi = bounds[i], bounds[i + 1]
+                ln = None if lens is None else lens[lo:hi]
                 if i == 0:
-                    self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi])
+                    self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi], lengths=ln)
                 else:
                     with torch.cuda.stream(pool[i - 1]):
-                        self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi])
+                        self.encode_audio(wav[lo:hi], max_patches, out=ea[lo:hi], lengths=ln)
             for st in pool:
                 cur.wait_stream(st)
-        return ea, et
+        return bank if packed else (ea, et)
 
     def _side_streams(self, n_split: int):
         key = max(1, n_split)
@@ -303,20 +361,31 @@ class CACO(_HipModel):
         return cache[key]
 
 
+def _bank(x: Tensor, what: str) -> Tensor:
+    """fp32 [N, D] with unit column stride and a row stride that is a multiple of 4 (a slice of a packed buffer is fine)."""
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    if x.dim() != 2:
+        raise ValueError(f"similarity: {what} must be [N, D], got {tuple(x.shape)}")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1] or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    return x
+
+
 def similarity(a: Tensor, t: Tensor, scale: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
-    """out[i, j] = scale * <a_i, t_j>, fp32 in / fp32 MFMA / fp32 out (C ABI: caco_similarity)."""
+    """out[i, j] = scale * <a_i, t_j>, fp32 in / fp32 MFMA / fp32 out (C ABI: caco_similarity_ld).  Row-strided banks
+    (views into a packed [N, 2, D] exchange buffer) are read in place."""
     lib = _lib.load()
     if a.device.type != "cuda" or t.device != a.device:
         raise RuntimeError("similarity: both embedding banks must be on the same GPU")
-    a = a.to(torch.float32).contiguous()
-    t = t.to(torch.float32).contiguous()
-    if a.dim() != 2 or t.dim() != 2 or a.shape[1] != t.shape[1]:
+    a, t = _bank(a, "audio bank"), _bank(t, "text bank")
+    if a.shape[1] != t.shape[1]:
         raise ValueError(f"similarity: expected [Na, D] and [Nt, D], got {tuple(a.shape)} and {tuple(t.shape)}")
     if out is None:
         out = torch.empty(a.shape[0], t.shape[0], dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.check(lib.caco_similarity(_ptr(a), a.shape[0], _ptr(t), t.shape[0], a.shape[1], float(scale), _ptr(out),
-                                       out.stride(0), _stream()), "similarity")
+        _lib.check(lib.caco_similarity_ld(_ptr(a), a.shape[0], a.stride(0), _ptr(t), t.shape[0], t.stride(0), a.shape[1],
+                                          float(scale), _ptr(out), out.stride(0), _stream()), "similarity")
     return out
 
 

@@ -36,6 +36,9 @@ def topk(sim: Tensor, k: int = 10, dim: int = -1) -> Tuple[Tensor, Tensor]:
     rows, cols = sim.shape
     if dim == 0:
         rows, cols, rs, cs = cols, rows, cs, rs
+    k = min(int(k), cols)          # argsort(-sim)[:, :k] has min(k, cols) columns; never hand out -1 padding for cols < k
+    if k < 1:
+        raise ValueError("topk: k must be >= 1 and the ranked axis non-empty")
     idx = torch.empty(rows, k, dtype=torch.int32, device=sim.device)
     val = torch.empty(rows, k, dtype=torch.float32, device=sim.device)
     with torch.cuda.device(sim.device):
@@ -73,7 +76,9 @@ def compute_retrieval_metric(indices, all_querys: Sequence, all_keys: Sequence, 
     indices = np.asarray(indices)
     R1, R5, R10, mAP10 = [], [], [], []
     for i, query in enumerate(all_querys):
-        pred_keys = [all_keys[int(idx)] for idx in indices[i, :10]]
+        # caco_topk pads a row with -1 when it has fewer than k selectable columns (cols < k, NaNs): the reference's
+        # indices[i, :10] is simply shorter there - a -1 must never index all_keys (Python would wrap to the LAST key)
+        pred_keys = [all_keys[int(idx)] for idx in indices[i, :10] if int(idx) >= 0]
         if retrieval_type == "at":
             preds, seen = [], []
             for pred in pred_keys:                      # a caption string counts once, and only if it belongs to this clip

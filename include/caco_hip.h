@@ -18,6 +18,11 @@
  *     (tower, stream), grown on demand: forwards enqueued on DIFFERENT streams (the text tower next to the audio
  *     tower, or two half batches) share no scratch memory and may overlap on the GPU; calls that share a stream
  *     are ordered by it.  Host-side the model is not thread safe: issue all calls from one thread.
+ *   - a caco_model lives on the device that was current at caco_create(); every entry point that takes a model returns
+ *     CACO_ERR_STATE when another device is current (kernel attributes, CU counts and the mel tables are kept per device,
+ *     so several models on several GPUs of one process are fine).
+ *   - process-global state: the two tuning knobs caco_set_gemm_tile / caco_set_ln_fold (the latter only as the default of
+ *     NEW models; caco_model_set_ln_fold acts on one model) and the caco_profile_* recorder (mutex-guarded).
  *   - row-major everywhere; Linear weights arrive in torch layout [out, in], fp32.
  */
 #ifndef CACO_HIP_H
@@ -56,6 +61,9 @@ typedef struct caco_config {
 } caco_config;
 
 const char* caco_version(void);
+/* sizeof(caco_config) as the library was built: a binding asserts it equals its own struct size before the first
+ * caco_default_config() (which memsets that many bytes) - cacophony_amd/_lib.py load() does. */
+int32_t caco_config_size(void);
 const char* caco_last_error(void);
 void caco_default_config(caco_config* cfg);
 
@@ -65,8 +73,8 @@ int caco_create(const caco_config* cfg, caco_model** out);
 void caco_destroy(caco_model* m);
 /* Upload one tensor by its reference state-dict key ("audio_module.layers.3.mlp.fc1.weight", ...;
  * AudioMAE keys are "encoder.*" / "decoder.*").  host_f32 is HOST memory, fp32, contiguous.
- * Unknown keys starting with "decoder_module." are accepted and ignored (captioning, out of scope);
- * any other unknown key, or a shape mismatch, is an error. */
+ * "decoder_module.*" (the caption decoder) is loaded when the model was created with caption_decoder_layers > 0 and
+ * accepted-and-ignored otherwise; any other unknown key, or a shape mismatch, is an error. */
 int caco_load_tensor(caco_model* m, const char* name, const float* host_f32, const int64_t* shape, int32_t ndim);
 /* Verify every required tensor arrived and build the packed bf16 operands.  Synchronises. */
 int caco_finalize_weights(caco_model* m);
@@ -90,6 +98,13 @@ int caco_mel_spectrogram(const float* wav_dev, int32_t batch, int64_t n_samples,
 int caco_mel_patches(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t max_patches, float scale,
                      float bias, void* patches_dev, int32_t patch_dtype, float* time_inds_dev, float* freq_inds_dev,
                      float* mask_dev, void* stream);
+/* The same for a batch of clips of DIFFERENT lengths, zero-padded to n_samples: lengths_dev int64 [batch] (NULL = all
+ * n_samples).  Clip b gets the patches / indices / mask the reference produces when prepare_audio_batch
+ * (src/eval/eval_caco_torch.py:181-206) runs on its lengths[b] samples alone: (ceil(len / 160) / 16) * 8 valid patches,
+ * the rest zero rows with mask 0. */
+int caco_mel_patches_lens(const float* wav_dev, const int64_t* lengths_dev, int32_t batch, int64_t n_samples,
+                          int32_t max_patches, float scale, float bias, void* patches_dev, int32_t patch_dtype,
+                          float* time_inds_dev, float* freq_inds_dev, float* mask_dev, void* stream);
 
 /* ---- encoders ---------------------------------------------------------------------------------
  * CACO.get_audio_embedding (src/caco_torch/caco.py:123-150):
@@ -106,6 +121,14 @@ int caco_text_forward(caco_model* m, const int64_t* ids_dev, const int64_t* mask
 /* encode_audio of BASELINE.json north_star = mel patches (bf16, on device) + get_audio_embedding(normalize=True). */
 int caco_encode_audio(caco_model* m, const float* wav_dev, int32_t batch, int64_t n_samples, int32_t max_patches,
                       float* emb_dev, void* stream);
+/* ... with per-clip lengths (lengths_dev int64 [batch] or NULL, see caco_mel_patches_lens) and an output row stride
+ * ld_emb (elements; 0 = projection_size): both towers can write straight into one packed [B, 2, P] exchange buffer
+ * (the all-gather payload of the data-parallel path, src/eval/eval_caco.py:53-64). */
+int caco_encode_audio_ex(caco_model* m, const float* wav_dev, const int64_t* lengths_dev, int32_t batch, int64_t n_samples,
+                         int32_t max_patches, float* emb_dev, int32_t ld_emb, void* stream);
+/* encode_text of north_star = get_text_embedding(normalize=True, position_ids=None) with an output row stride. */
+int caco_encode_text(caco_model* m, const int64_t* ids_dev, const int64_t* mask_dev, int32_t batch, int32_t seq,
+                     float* emb_dev, int32_t ld_emb, void* stream);
 
 /* ---- scoring ----------------------------------------------------------------------------------
  * out[i, j] = scale * <a_i, t_j>: CACO.get_contrastive_logits' matmul (src/caco_torch/caco.py:208-210)
@@ -113,6 +136,9 @@ int caco_encode_audio(caco_model* m, const float* wav_dev, int32_t batch, int64_
  * a_dev [na, dim], t_dev [nt, dim], out_dev [na, nt] with row stride ld_out (>= nt). */
 int caco_similarity(const float* a_dev, int32_t na, const float* t_dev, int32_t nt, int32_t dim, float scale,
                     float* out_dev, int32_t ld_out, void* stream);
+/* ... with row strides lda / ldt (elements, 0 = dim, multiples of 4) for banks that live interleaved in a packed buffer */
+int caco_similarity_ld(const float* a_dev, int32_t na, int32_t lda, const float* t_dev, int32_t nt, int32_t ldt, int32_t dim,
+                       float scale, float* out_dev, int32_t ld_out, void* stream);
 /* Retrieval scoring, device part: the first k columns of argsort(-sim, dim=-1) per row
  * (src/eval/eval_caco_torch.py:402-408; src/eval/eval_utils.py:18-54 reads only the first 10).  sim_dev is read
  * as sim[r * row_stride + c * col_stride] (elements), so audio->text (rows = clips) and text->audio (rows = captions)
@@ -165,16 +191,19 @@ void caco_decode_end(caco_decode_state* s);
 
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 int64_t caco_workspace_bytes(const caco_model* m);
-/* Tuning knob: bf16 GEMM kernel choice.  256 (default) = the 256x128 two-workgroups-per-CU kernel when its grid
- * covers the chip, else the 128x128 kernel; 128 = always 128x128 (env CACO_GEMM_TILE=128 selects it at first use);
- * 2256 / 1256 = force the 256x128 kernel / the one-workgroup-per-CU 256x256 phased kernel (tests, A/B runs).
- * Returns the mode now in force; any other value only queries. */
+/* Tuning knob (process-global): bf16 GEMM kernel choice.  256 (default) = per shape: the persistent 256x256 eight-wave
+ * kernel (csrc/gemm_w8.hip) when every CU gets work, else the 256x128 two-workgroups-per-CU kernel (gemm_x.hip), else
+ * 128x128; 128 = always 128x128 (env CACO_GEMM_TILE=128 selects it at first use).  Forced kernels for tests / A-B runs:
+ * 8256 = gemm_w8, 2256 = gemm_x, 6256 = gemm_s8.hip (w8 with the epilogue under its own K-loop; measured a draw).  A
+ * forced kernel that does not support a shape falls back to the default choice.  Returns the mode now in force; any
+ * other value only queries. */
 int32_t caco_set_gemm_tile(int32_t tile);
 /* Tuning knob: LayerNorm folding in the audio stack (the LayerNorm passes disappear into the neighbouring GEMM
  * epilogues; api.hip run_audio_layers).  0 = separate LayerNorm passes (default: measured slightly faster at batch
  * 256, see api.hip), 1 = always fold, -1 = fold when the batch fills the chip.  Env CACO_LN_FOLD sets the initial
  * mode.  Returns the mode now in force; any other value only queries. */
-int32_t caco_set_ln_fold(int32_t mode);
+int32_t caco_set_ln_fold(int32_t mode);             /* the default of models created afterwards */
+int32_t caco_model_set_ln_fold(caco_model* m, int32_t mode);   /* one model */
 /* Per-stage timing.  While enabled, every forward records a hipEvent pair around each launch group on the
  * caller's stream.  caco_profile_report synchronises on them, writes a JSON object
  * {"audio.gemm_fc1": {"ms": total, "n": launches}, ...} into buf (truncated to buflen) and resets the
@@ -200,10 +229,6 @@ int caco_op_layernorm(const float* x_dev, const float* gamma_dev, const float* b
 int caco_op_attention(const void* qkv_dev, int32_t ld, int32_t k_off, int32_t v_off, const float* key_mask_dev,
                       int32_t batch, int32_t seq, int32_t heads, int32_t head_dim, int32_t causal, void* out_dev,
                       void* stream);
-/* Tuning knob (experiment): 1 routes non-causal attention with >= 128 query rows to the two-pass 64-rows-per-wave
- * kernel (csrc/attention64.hip; env CACO_ATTN64=1 selects it at first use).  Default 0: measured slower.  Returns the
- * setting in effect. */
-int caco_set_attention64(int32_t on);
 /* The same kernel with separate operands (cross-attention, RobertaSelfAttention with key_value_states,
  * roberta.py:67-104): queries q_dev bf16 [B*seq_q, q_ld] (head h at column h*head_dim), keys / values kv_dev bf16
  * [B*seq, ld] at columns k_off / v_off, key_mask_dev fp32 [B, seq] or NULL -> out_dev bf16 [B*seq_q, heads*head_dim].

@@ -76,3 +76,30 @@ def test_spectrogram_to_patches_host_mirror_matches_oracle():
         a, b = spectrogram_to_patches(spec, 16, 16, max_p), O.spectrogram_to_patches(spec, 16, 16, max_p)
         for k in b:
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_integration_doc_struct_matches_header_and_binding():
+    """INTEGRATION.md section 2 shows the ctypes struct a maintainer would copy: its field list must be the header's
+    (round 1 shipped it one field short: caco_default_config memsets sizeof(caco_config) -> 4-byte overflow)."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "caco_hip.h")).read()
+    body = re.search(r"typedef struct caco_config \{(.*?)\} caco_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    header_fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        header_fields += [(n.strip(), typ) for n in names.split(",")]
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    snippet = doc[doc.index("class caco_config(C.Structure):"):doc.index("lib.caco_config_size.restype")]
+    ns = {"C": C}
+    exec(snippet, ns)
+    doc_fields = [(n, "float" if t is C.c_float else "int32_t") for n, t in ns["caco_config"]._fields_]
+    assert doc_fields == header_fields
+    assert [(n, "float" if t is C.c_float else "int32_t") for n, t in _lib.CacoConfigC._fields_] == header_fields
+    lib = _lib.load()
+    assert lib.caco_config_size() == C.sizeof(ns["caco_config"]) == C.sizeof(_lib.CacoConfigC) == 4 * len(header_fields)

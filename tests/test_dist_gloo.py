@@ -30,6 +30,18 @@ def _worker(rank, world, port, out_dir):
         assert hi - lo == per
         ga, gt = cdist.gather_embedding_banks(a_all[lo:hi], t_all[lo:hi])
         assert torch.equal(ga, a_all) and torch.equal(gt, t_all)
+        # the packed form the towers fill directly: one collective, banks come back as strided views in rank order
+        bank = torch.stack([a_all[lo:hi], t_all[lo:hi]], 1).contiguous()
+        allb = cdist.gather_packed(bank, check_sizes=True)
+        assert allb.shape == (world * per, 2, 32) and torch.equal(allb[:, 0], a_all) and torch.equal(allb[:, 1], t_all)
+        # unequal shards (what shard_range hands out when the global count does not divide) are refused, not hung on
+        n_bad = per + (1 if rank == 0 else 0)
+        try:
+            cdist.gather_embedding_banks(torch.zeros(n_bad, 32), torch.zeros(n_bad, 32))
+            raised = False
+        except ValueError:
+            raised = True
+        assert raised
         block = cdist.sharded_similarity(a_all[lo:hi], t_all[lo:hi], scale=2.0,
                                          similarity_fn=lambda a, t, s: s * a @ t.T)
         ref = 2.0 * a_all @ t_all.T

@@ -40,7 +40,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(DEV)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 1256, 2256, 4256, 8256, 9256, 5256])
+@pytest.mark.parametrize("tile", [128, 256, 2256, 8256])
 @pytest.mark.parametrize("M,N,K,act", [(1000, 768, 256, 0), (4096, 1536, 768, 0), (2500, 3072, 768, 1),
                                        (2048, 768, 3072, 0), (8192, 3072, 768, 2), (300, 256, 768, 0),
                                        (777, 768, 64, 0), (5000, 256, 128, 1)])
@@ -64,7 +64,7 @@ def test_gemm_bf16(lib, tile, M, N, K, act):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 1256, 2256, 4256, 8256, 9256, 5256])
+@pytest.mark.parametrize("tile", [128, 256, 2256, 8256])
 def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(tile)
     M, N, K = 3001, 768, 3072
@@ -83,7 +83,7 @@ def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [256, 1256, 8256, 4256, 9256, 5256])
+@pytest.mark.parametrize("tile", [256, 8256, 6256])
 @pytest.mark.parametrize("M,N,K,kind", [(70000, 768, 768, "f32r"), (33333, 768, 3072, "f32r"), (50000, 2304, 768, "bf16"),
                                         (45000, 3072, 768, "silu")])
 def test_gemm_persistent_multi_tile_pipeline(lib, tile, M, N, K, kind):
@@ -175,18 +175,10 @@ def _attention_ref(qk, v, key_mask, heads, hd, causal):
     return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, S, H)
 
 
-@pytest.fixture(params=[0, 1], ids=["attn32", "attn64_two_pass"])
-def attn_kernel(request, lib):
-    """both non-causal kernels: the default and the opt-in two-pass 64-rows-per-wave form (csrc/attention64.hip)"""
-    assert lib.caco_set_attention64(request.param) == request.param
-    yield request.param
-    lib.caco_set_attention64(0)
-
-
 @pytest.mark.parametrize("B,S,heads,hd,causal,valid", [
     (2, 500, 8, 96, 0, [496, 144]), (3, 32, 12, 64, 1, [32, 12, 1]), (1, 1500, 8, 96, 0, [1496]),
     (2, 100, 12, 64, 1, [100, 37]), (2, 64, 8, 96, 0, [64, 64]), (1, 130, 8, 96, 1, [129])])
-def test_attention(lib, B, S, heads, hd, causal, valid, attn_kernel):
+def test_attention(lib, B, S, heads, hd, causal, valid):
     H = heads * hd
     qk = _rand((B, S, 2 * H), 20, 1.5).bfloat16()
     v = _rand((B, S, H), 21).bfloat16()
@@ -211,7 +203,7 @@ def test_attention(lib, B, S, heads, hd, causal, valid, attn_kernel):
 @pytest.mark.parametrize("B,Sq,S,heads,hd,valid", [
     (2, 32, 500, 12, 64, [496, 144]), (3, 1, 500, 12, 64, [500, 7, 1]), (2, 20, 70, 12, 64, [50, 70]),
     (1, 200, 33, 8, 96, [33]), (2, 129, 64, 12, 64, [64, 5])])
-def test_cross_attention(lib, B, Sq, S, heads, hd, valid, attn_kernel):
+def test_cross_attention(lib, B, Sq, S, heads, hd, valid):
     """queries and keys/values from different buffers and lengths (caption decoder cross-attention, roberta.py:67-104)."""
     H = heads * hd
     q = _rand((B, Sq, H), 40, 1.5).bfloat16()

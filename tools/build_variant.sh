@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 python -m cacophony_amd.build >/dev/null
 mkdir -p cacophony_amd/_variants
 OBJ=cacophony_amd/_variants/${SRC%.hip}_$NAME.o
-EXTRA=""; if [ "$SRC" = attention64.hip ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi     # = cacophony_amd/build.py EXTRA_FLAGS
+EXTRA=""
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast $EXTRA -I include "$@" -c cacophony_amd/csrc/$SRC -o $OBJ
 OTHERS=$(ls cacophony_amd/csrc/_obj/*.o | grep -v "/${SRC%.hip}.o")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o cacophony_amd/_variants/libcaco_hip_$NAME.so $OBJ $OTHERS

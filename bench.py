@@ -46,6 +46,7 @@ if REPO not in sys.path:
 B_PER_GPU = 256
 N_SAMPLES = 160000
 SEQ = 500          # 496 valid patches padded to patches_seq_len = 500 (src/eval/eval_caco_torch.py:573)
+SEQ_RUN = 496      # what the audio tower runs on: encode_audio drops the 4 all-padding positions (api.hip caco_encode_audio_ex)
 TEXT_LEN = 32
 H, I, P = 768, 3072, 256
 PEAK_BF16_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
@@ -56,8 +57,8 @@ DRYRUN = os.environ.get("CACO_BENCH_DRYRUN", "0") not in ("", "0")
 
 # algorithmic FLOPs (2 * MACs) per launch group at batch 256; SURVEY.md section 8d
 def _flops(batch):
-    M, Mt = batch * SEQ, batch * TEXT_LEN
-    S_attn = 2 * 2 * SEQ * SEQ * H            # QK^T + PV per clip, all heads
+    M, Mt = batch * SEQ_RUN, batch * TEXT_LEN
+    S_attn = 2 * 2 * SEQ_RUN * SEQ_RUN * H    # QK^T + PV per clip, all heads
     T_attn = 2 * 2 * TEXT_LEN * TEXT_LEN * H
     return {
         "audio.patch_embed": 2 * M * P * H, "audio.gemm_qkv": 2 * M * H * 3 * H,
@@ -75,7 +76,7 @@ def _audio_tower_flops(batch):
 
 
 def _bytes(batch):
-    M = batch * SEQ
+    M = batch * SEQ_RUN
     return {
         "mel.patches": batch * (N_SAMPLES * 4 + 496 * 256 * 2),      # fp32 samples in + bf16 patches out
         "audio.ln": M * H * (4 + 2),                                  # fp32 residual in, bf16 operand out
@@ -317,7 +318,7 @@ def main():
         except Exception:
             traffic = None
         if dom:
-            roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [128000,768] x [3072,768]^T)",
+            roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [126976,768] x [3072,768]^T)",
                         "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],

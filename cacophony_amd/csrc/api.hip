@@ -1093,6 +1093,15 @@ int caco_encode_audio_ex(caco_model* m, const float* wav, const int64_t* lengths
                "caco_encode_audio: the fused front end needs patch_size 256 / num_freq_patches 8 (model has %d / %d)",
                m->cfg.patch_size, m->cfg.num_freq_patches);
   hipStream_t st = (hipStream_t)stream;
+  // Only the embedding leaves this entry point, and a padded patch (mask 0) can neither be attended to nor pooled: the tower
+  // runs on the patches the longest clip really has - 496 of the reference's patches_seq_len = 500 for 10 s clips
+  // (eval_caco_torch.py:573: 0.8 % of every GEMM / LayerNorm / attention row) - instead of on the padded window.
+  // (caco_audio_forward keeps the caller's S: it returns hidden states for every position, padded ones included.)
+  {
+    static const int keep_pad = getenv("CACO_KEEP_PAD") ? atoi(getenv("CACO_KEEP_PAD")) : 0;
+    const int64_t full = ((n_samples + 159) / 160 / 16) * 8;
+    if (!keep_pad && full >= 1 && full < max_patches) max_patches = (int32_t)full;
+  }
   // front-end outputs live in their own arena so that the forward's arena growth cannot move them
   const size_t n_tok = (size_t)batch * max_patches;
   Arena F(m, WS_FRONTEND, st);

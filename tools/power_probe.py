@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Is a kernel power-limited?  Runs one GEMM shape back to back for a few seconds on random / zero operands (and optionally a
+forced kernel) while sampling rocm-smi: average socket power, sclk.  Same instruction stream, different operand bits.
+   python tools/power_probe.py [--only fc1] [--tile 256] [--seconds 3]"""
+import argparse
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cacophony_amd import _lib  # noqa: E402
+
+SHAPES = {"qkv": (128000, 2304, 768, "bf16", 0), "fc1": (128000, 3072, 768, "bf16", 1), "fc2": (128000, 768, 3072, "f32r", 0)}
+
+
+def sample(stop, out):
+    while not stop.is_set():
+        try:
+            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "-d", "0"], capture_output=True, text=True, timeout=5).stdout
+            p = re.search(r"Power \(W\):\s*([0-9.]+)", r)
+            c = re.search(r"sclk clock level:.*\((\d+)Mhz\)", r)
+            out.append((float(p.group(1)) if p else None, int(c.group(1)) if c else None))
+        except Exception as e:
+            out.append((None, None))
+        time.sleep(0.15)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="fc1")
+    ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=3.0)
+    a = ap.parse_args()
+    lib = _lib.load()
+    lib.caco_set_gemm_tile(a.tile)
+    dev = "cuda:0"
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name in a.only.split(","):
+        M, N, K, kind, act = SHAPES[name]
+        for data in ("randn", "zeros"):
+            A = torch.randn(M, K, device=dev).bfloat16()
+            W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+            if data == "zeros":
+                A.zero_(); W.zero_()
+            bias = torch.randn(N, device=dev)
+            if kind == "bf16":
+                out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+                run = lambda: lib.caco_op_gemm_bf16(p(A), p(W), p(bias), M, N, K, act, p(out), st)
+            else:
+                out = torch.randn(M, N, device=dev)
+                run = lambda: lib.caco_op_gemm_bf16_f32out(p(A), p(W), p(bias), p(out), M, N, K, p(out), st)
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            stop, samples = threading.Event(), []
+            th = threading.Thread(target=sample, args=(stop, samples))
+            th.start()
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < a.seconds:
+                for _ in range(50):
+                    run()
+                torch.cuda.synchronize()
+                n += 50
+            dt = time.perf_counter() - t0
+            stop.set(); th.join()
+            pw = [s[0] for s in samples[1:] if s[0]]
+            ck = [s[1] for s in samples[1:] if s[1]]
+            tf = 2.0 * M * N * K * n / dt / 1e12
+            print(f"{name} tile {a.tile} {data:5s}: {dt / n * 1e6:7.1f} us  {tf:7.1f} TFLOP/s  power avg {sum(pw) / max(1, len(pw)):.0f} W (max {max(pw, default=0):.0f})  "
+                  f"sclk avg {sum(ck) / max(1, len(ck)):.0f} MHz (min {min(ck, default=0)})  [{len(pw)} samples]", flush=True)
+
+
+if __name__ == "__main__":
+    main()

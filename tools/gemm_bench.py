@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cacophony_amd import _lib  # noqa: E402
 
 SHAPES = {  # name: (M, N, K, kind, act)
-    "qkv": (128000, 2304, 768, "bf16", 0), "out": (128000, 768, 768, "f32r", 0),
-    "fc1": (128000, 3072, 768, "bf16", 1), "fc2": (128000, 768, 3072, "f32r", 0), "embed": (128000, 768, 256, "f32", 0),
+    "qkv": (126976, 2304, 768, "bf16", 0), "out": (126976, 768, 768, "f32r", 0),
+    "fc1": (126976, 3072, 768, "bf16", 1), "fc2": (126976, 768, 3072, "f32r", 0), "embed": (126976, 768, 256, "f32", 0),
     "t_qkv": (8192, 2304, 768, "bf16", 0), "t_out": (8192, 768, 768, "f32r", 0), "t_fc1": (8192, 3072, 768, "bf16", 2), "t_fc2": (8192, 768, 3072, "f32r", 0),
 }
 

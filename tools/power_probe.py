@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cacophony_amd import _lib  # noqa: E402
 
-SHAPES = {"qkv": (128000, 2304, 768, "bf16", 0), "fc1": (128000, 3072, 768, "bf16", 1), "fc2": (128000, 768, 3072, "f32r", 0)}
+SHAPES = {"qkv": (126976, 2304, 768, "bf16", 0), "fc1": (126976, 3072, 768, "bf16", 1), "fc2": (126976, 768, 3072, "f32r", 0)}
 
 
 def sample(stop, out):
@@ -31,12 +31,67 @@ def sample(stop, out):
         time.sleep(0.15)
 
 
+def measure(name, run, seconds, flops=None, chunk=20):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    stop, samples = threading.Event(), []
+    th = threading.Thread(target=sample, args=(stop, samples))
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(chunk):
+            run()
+        torch.cuda.synchronize()
+        n += chunk
+    dt = time.perf_counter() - t0
+    stop.set(); th.join()
+    pw = [s[0] for s in samples[1:] if s[0]]
+    ck = [s[1] for s in samples[1:] if s[1]]
+    tf = f"{flops * n / dt / 1e12:7.1f} TFLOP/s  " if flops else ""
+    print(f"{name}: {dt / n * 1e6:9.1f} us  {tf}power avg {sum(pw) / max(1, len(pw)):.0f} W (max {max(pw, default=0):.0f})  "
+          f"sclk avg {sum(ck) / max(1, len(ck)):.0f} MHz (min {min(ck, default=0)})  [{len(pw)} samples]", flush=True)
+
+
+def stages(seconds):
+    """The whole step and its non-GEMM kernels: which of them sit at the power cap?"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from cacophony_amd import config as Cfg, synth
+    from cacophony_amd.model import create_caco_model
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    state = synth.make_caco_state(Cfg.default_audio_config(), Cfg.default_text_config(), Cfg.default_caco_config())
+    model = create_caco_model(device=dev).load_state_dict(state)
+    wav, ids, mask = bench._make_inputs(256, 0, dev)
+    measure("step (encode_pairs, both towers)", lambda: model.encode_pairs(wav, ids, mask, 500), seconds, chunk=3)
+    measure("audio tower only", lambda: model.encode_audio(wav, 500), seconds, chunk=3)
+    measure("text tower only", lambda: model.encode_text(ids, mask, check_ids=False), seconds, chunk=10)
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, S, heads, hd = 256, 496, 8, 96
+    H = heads * hd
+    qkv = torch.randn(B * S, 2560, device=dev).bfloat16()
+    km = torch.ones(B, S, device=dev)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
+    measure("attention S=496", lambda: lib.caco_op_attention(p(qkv), 2560, H, 2 * H, p(km), B, S, heads, hd, 0, p(out), st), seconds,
+            flops=2 * 2 * S * S * H * B)
+    x = torch.randn(B * S, H, device=dev)
+    g = torch.ones(H, device=dev)
+    ob = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
+    measure("layernorm", lambda: lib.caco_op_layernorm(p(x), p(g), p(g), B * S, H, 1e-5, None, p(ob), st), seconds)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--stages", action="store_true")
     ap.add_argument("--only", default="fc1")
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=3.0)
     a = ap.parse_args()
+    if a.stages:
+        return stages(a.seconds)
     lib = _lib.load()
     lib.caco_set_gemm_tile(a.tile)
     dev = "cuda:0"

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cacophony_amd import _lib  # noqa: E402
 
-SHAPES = {"qkv": (128000, 2304, 768, 0), "fc1": (128000, 3072, 768, 1)}
+SHAPES = {"qkv": (126976, 2304, 768, 0), "fc1": (126976, 3072, 768, 1)}
 lib = _lib.load()
 lib.caco_set_gemm_tile(6256)
 dev = "cuda:0"

@@ -12,8 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cacophony_amd import _lib  # noqa: E402
 
-SHAPES = {"qkv": (128000, 2304, 768, "bf16", 0), "out": (128000, 768, 768, "f32r", 0), "fc1": (128000, 3072, 768, "bf16", 1),
-          "fc2": (128000, 768, 3072, "f32r", 0)}
+SHAPES = {"qkv": (126976, 2304, 768, "bf16", 0), "out": (126976, 768, 768, "f32r", 0), "fc1": (126976, 3072, 768, "bf16", 1),
+          "fc2": (126976, 768, 3072, "f32r", 0)}
 lib = _lib.load()
 lib.caco_set_gemm_tile(256)
 dev = "cuda:0"

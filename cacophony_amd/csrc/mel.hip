@@ -25,28 +25,33 @@ namespace {
 
 constexpr int HOP = 160, WIN = 400, NFFT = 512, NMEL = 128, NBIN = 257, WOFF = (NFFT - WIN) / 2;
 constexpr int FPB = 16;                               // frames per workgroup
-constexpr int SPAN = (FPB - 1) * HOP + WIN;           // 2800 samples feed one workgroup
-constexpr int SPAN_PAD = 2816;
-constexpr int MELW_MAX = 640;
+constexpr int SOFF = 32;                              // first sample a frame's FFT ever reads: taps below 56 carry a zero window
+constexpr int SPAN = (FPB - 1) * HOP + NFFT - 2 * SOFF;   // 2848 samples feed one workgroup
+// HTK filter supports at 16 kHz / 257 bins, as the maximum over each group of 16 consecutive filters (thread t owns filters
+// t, t+16, ...): 38 multiply-adds per thread, weights zero-padded to the group maximum.  ensure_tables() checks the
+// filterbank it builds against these bounds.
+constexpr int MEL_GROUP_TAPS[NMEL / 16] = {2, 2, 2, 3, 4, 6, 8, 11};
+constexpr int MEL_TAPS = 2 + 2 + 2 + 3 + 4 + 6 + 8 + 11;
 
-struct MelTables {            // device image, loaded verbatim into LDS
-  float hann[WIN];
-  float tw256[512];           // e^{-2 pi i n1 k2 / 256}, index (n1*16 + k2), interleaved re/im
-  float tw512[516];           // e^{-2 pi i k / 512}, k = 0..256 (+ pad)
-  float melw[MELW_MAX];       // CSR weights
+struct MelTables {            // device image; the first LDS_FLOATS floats are staged into LDS verbatim
+  float tw256[512];           // e^{-2 pi i n1 k2 / 256}, index (n1*16 + k2) (symmetric), interleaved re/im
+  float tw512[512];           // e^{-2 pi i k / 512}, k = 0..255
+  float hann512[NFFT];        // periodic Hann(400) centred in the 512-point frame, zeros outside
+  float melw[MEL_TAPS * 16];  // [tap slot][t]: weight of thread t's filter t + 16 j at bin mel_start + i
   int mel_start[NMEL];        // first bin of filter m
-  int mel_off[NMEL];          // offset of its weights in melw
-  int mel_cnt[NMEL];          // number of non-zero bins
 };
+constexpr int LDS_FLOATS = 1024;
 static_assert(sizeof(MelTables) % 16 == 0, "MelTables must be float4-copyable");
 
 constexpr int XP = 272;       // complex pitch per frame: 16*17, and 2*XP = 32 (mod 64) banks
 
 struct __attribute__((aligned(16))) MelSmem {
-  float samp[SPAN_PAD];             // samples, later the [16][128] log-mel tile
-  MelTables tab;
+  float samp[SPAN];                 // samples, later the [16][128] log-mel tile
+  float tw256[512];
+  float tw512[512];
   float2 buf[FPB * XP];             // FFT transposition / spectrum, later magnitudes
 };
+static_assert(SPAN % 4 == 0 && SPAN >= FPB * NMEL, "sample span is float4-copyable and holds the log-mel tile");
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -93,8 +98,15 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 }
 
 // MODE: MEL_NATURAL_F32 -> out fp32 [B, frames_out, 128]; MEL_PATCH_F32 / MEL_PATCH_BF16 -> [B, S, 256]
+//
+// Instruction budget (the kernel is VALU/LDS-issue bound, not HBM bound: 9e7 wave instructions per batch of 256 clips in
+// round 1).  Everything a thread needs that does not change from block to block lives in registers for the life of the
+// workgroup (its 28 window taps, its 38 filter weights and 8 filter starts); the window is a zero-padded 512-tap table so
+// pass A has no lane-dependent branch, taps n2 = 0 and 15 are compile-time zeros, the filterbank loop is fully unrolled
+// with compile-time trip counts, and the magnitude uses the raw v_sqrt_f32 (1 ulp; no denormal rescue sequence).
+static_assert(sizeof(MelSmem) * 2 <= 160 * 1024, "two workgroups per CU");
 template <int MODE>
-__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int64_t n_samples,
+__global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ wav, int64_t n_samples,
                                                   const MelTables* __restrict__ tables, void* __restrict__ out,
                                                   int frames_out, int rows_out, int S, float scale, float bias, int nblk) {
   __shared__ MelSmem sm;
@@ -105,14 +117,23 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
   // ---- constant tables: staged ONCE per workgroup; the workgroup then walks several 16-frame blocks ----------
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(tables);
-    f32x4* dst = reinterpret_cast<f32x4*>(&sm.tab);
-    for (int i = tid; i < (int)(sizeof(MelTables) / 16); i += 256) dst[i] = src[i];
+    f32x4* dst = reinterpret_cast<f32x4*>(sm.tw256);
+    for (int i = tid; i < LDS_FLOATS / 4; i += 256) dst[i] = src[i];
   }
+  float2 hreg[14];                       // window taps of complex samples n = t + 16 n2, n2 = 1..14
+#pragma unroll
+  for (int n2 = 1; n2 < 15; ++n2) hreg[n2 - 1] = *reinterpret_cast<const float2*>(&tables->hann512[2 * (t + 16 * n2)]);
+  float wreg[MEL_TAPS];
+#pragma unroll
+  for (int i = 0; i < MEL_TAPS; ++i) wreg[i] = tables->melw[i * 16 + t];
+  int mstart[NMEL / 16];
+#pragma unroll
+  for (int j = 0; j < NMEL / 16; ++j) mstart[j] = tables->mel_start[t + 16 * j];
   const bool vec_ok = (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(wav) & 15) == 0;
 
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int f0 = blk * FPB;
-    const int64_t g0 = (int64_t)f0 * HOP + WOFF;
+    const int64_t g0 = (int64_t)f0 * HOP + SOFF;
     __syncthreads();          // previous block's tile (aliases samp) fully stored; tables visible on the first pass
     if (vec_ok) {
       for (int i = tid; i < SPAN / 4; i += 256) {
@@ -135,24 +156,25 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     // wave execute in order, so wave-level ordering (no workgroup barrier) is enough between the passes.
     // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
     float2 v[16];
+    {
+      const float2* sp = reinterpret_cast<const float2*>(&sm.samp[fl * HOP - SOFF]) + t;   // complex sample n at sp[n - t]
+      v[0] = make_float2(0.f, 0.f);            // n < 16: real samples < 32, window zero
+      v[15] = make_float2(0.f, 0.f);           // n >= 240: real samples >= 480, window zero
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
-      const int n = t + 16 * n2;                 // complex index; real samples 2n, 2n+1 of the 512 frame
-      float2 z = make_float2(0.f, 0.f);
-      if (n >= WOFF / 2 && n < (WOFF + WIN) / 2) {
-        const int wi = 2 * n - WOFF;             // window tap of the even sample
-        const float2 x = *reinterpret_cast<const float2*>(&sm.samp[fl * HOP + wi]);
-        const float2 h = *reinterpret_cast<const float2*>(&sm.tab.hann[wi]);
-        z = make_float2(x.x * h.x, x.y * h.y);
+      for (int n2 = 1; n2 < 15; ++n2) {
+        const float2 x = sp[16 * n2];
+        v[n2] = make_float2(x.x * hreg[n2 - 1].x, x.y * hreg[n2 - 1].y);
       }
-      v[n2] = z;
     }
     dft16(v);
     {
-      const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw256) + t * 16;
+      // W256^(n1 k2) is symmetric in (n1, k2): read it as [k2][n1 = t] so that the 16 lanes of a frame fetch consecutive
+      // words (as [t][k2] the lane stride was 128 bytes: an 8-way bank conflict on every one of the 16 reads)
+      const float2* tw = reinterpret_cast<const float2*>(sm.tw256) + t;
       float2* col = sm.buf + fl * XP + t * 17;
+      col[0] = v[0];                           // W^0
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2]);
+      for (int k2 = 1; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2 * 16]);
     }
     __builtin_amdgcn_wave_barrier();
     // ---- pass B: thread k2 = t transforms over n1 -> X[k2 + 16 k1] -----------------------------------
@@ -165,44 +187,46 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
     __builtin_amdgcn_wave_barrier();
 
     // ---- real-input split + magnitude: R[k] = ((Zk + conj Z-k) - i w^k (Zk - conj Z-k)) / 2 ----------
-    float mag[17];
+    float mag[16], mag256;
     {
       const float2* X = sm.buf + fl * XP;
-      const float2* tw = reinterpret_cast<const float2*>(sm.tab.tw512);
+      const float2* tw = reinterpret_cast<const float2*>(sm.tw512) + t;
 #pragma unroll
-      for (int j = 0; j < 17; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int k = t + 16 * j;
-        float m = 0.f;
-        if (k <= 256) {
-          const float2 zk = X[k & 255];
-          const float2 zr = X[(256 - k) & 255];
-          const float2 zc = make_float2(zr.x, -zr.y);
-          const float2 e = cadd(zk, zc), d = csub(zk, zc);
-          const float2 wd = cmul(tw[k], d);
-          const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
-          m = sqrtf(re * re + im * im);
-        }
-        mag[j] = m;
+        const float2 zk = X[k];
+        const float2 zr = X[(256 - k) & 255];
+        const float2 zc = make_float2(zr.x, -zr.y);
+        const float2 e = cadd(zk, zc), d = csub(zk, zc);
+        const float2 wd = cmul(tw[16 * j], d);
+        const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
+        mag[j] = __builtin_amdgcn_sqrtf(re * re + im * im);
       }
+      const float2 z0 = X[0];
+      mag256 = fabsf(z0.x - z0.y);             // R[256] = Re Z0 - Im Z0 (real)
     }
     __builtin_amdgcn_wave_barrier();
-    float* magbuf = reinterpret_cast<float*>(sm.buf) + fl * (2 * XP);     // inside this frame's own spectrum region
+    // inside this frame's own spectrum region (544 floats for 257 magnitudes); odd frames are shifted by 16 floats so that
+    // the two frames of a 32-lane ds_read_b32 group do not gather from identical banks (544 = 0 mod 32)
+    float* magbuf = reinterpret_cast<float*>(sm.buf) + fl * (2 * XP) + (fl & 1) * 16;
 #pragma unroll
-    for (int j = 0; j < 17; ++j) {
-      const int k = t + 16 * j;
-      if (k <= 256) magbuf[k] = mag[j];
-    }
+    for (int j = 0; j < 16; ++j) magbuf[t + 16 * j] = mag[j];
+    if (t == 0) magbuf[256] = mag256;
     __builtin_amdgcn_wave_barrier();
 
-    // ---- mel filterbank (CSR gather) + log; thread owns mels t, t+16, ... ------------------------------
+    // ---- mel filterbank + log; thread owns mels t, t+16, ...: compile-time trip counts, weights in registers -------------
     float melv[NMEL / 16];
+    {
+      int slot = 0;
 #pragma unroll
-    for (int j = 0; j < NMEL / 16; ++j) {
-      const int m = t + 16 * j;
-      const int st = sm.tab.mel_start[m], off = sm.tab.mel_off[m], cnt = sm.tab.mel_cnt[m];
-      float acc = 0.f;
-      for (int i = 0; i < cnt; ++i) acc += magbuf[st + i] * sm.tab.melw[off + i];
-      melv[j] = __logf(acc + 1e-5f) * scale + bias;
+      for (int j = 0; j < NMEL / 16; ++j) {
+        const float* mp = magbuf + mstart[j];
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MEL_GROUP_TAPS[j]; ++i) acc += mp[i] * wreg[slot + i];
+        slot += MEL_GROUP_TAPS[j];
+        melv[j] = __logf(acc + 1e-5f) * scale + bias;
+      }
     }
     __syncthreads();                            // every frame is done reading the samples: samp becomes the tile
     float* tile = sm.samp;                      // [16 frames][128 mels]
@@ -285,14 +309,14 @@ int ensure_tables(MelTables** out) {
   std::vector<char> hostbuf(sizeof(MelTables), 0);
   MelTables* h = reinterpret_cast<MelTables*>(hostbuf.data());
   const double PI = 3.14159265358979323846;
-  for (int k = 0; k < WIN; ++k) h->hann[k] = (float)(0.5 - 0.5 * cos(2.0 * PI * k / WIN));   // periodic
+  for (int k = 0; k < WIN; ++k) h->hann512[WOFF + k] = (float)(0.5 - 0.5 * cos(2.0 * PI * k / WIN));   // periodic; zeros outside
   for (int n1 = 0; n1 < 16; ++n1)
     for (int k2 = 0; k2 < 16; ++k2) {
       const double a = -2.0 * PI * (double)(n1 * k2) / 256.0;
       h->tw256[2 * (n1 * 16 + k2)] = (float)cos(a);
       h->tw256[2 * (n1 * 16 + k2) + 1] = (float)sin(a);
     }
-  for (int k = 0; k <= 256; ++k) {
+  for (int k = 0; k < 256; ++k) {
     const double a = -2.0 * PI * (double)k / 512.0;
     h->tw512[2 * k] = (float)cos(a);
     h->tw512[2 * k + 1] = (float)sin(a);
@@ -301,8 +325,10 @@ int ensure_tables(MelTables** out) {
   const double f_max = 8000.0, m_max = 2595.0 * log10(1.0 + f_max / 700.0);
   std::vector<double> f_pts(NMEL + 2);
   for (int i = 0; i < NMEL + 2; ++i) f_pts[i] = 700.0 * (pow(10.0, (m_max * i / (NMEL + 1)) / 2595.0) - 1.0);
-  int off = 0;
+  int slot0[NMEL / 16];
+  for (int j = 0, s0 = 0; j < NMEL / 16; ++j) { slot0[j] = s0; s0 += MEL_GROUP_TAPS[j]; }
   for (int m = 0; m < NMEL; ++m) {
+    const int t = m % 16, j = m / 16;
     int start = -1, cnt = 0;
     for (int k = 0; k < NBIN; ++k) {
       const double f = 8000.0 * k / (NBIN - 1);
@@ -311,18 +337,21 @@ int ensure_tables(MelTables** out) {
       const double wgt = fmax(0.0, fmin(down, up));
       if (wgt > 0.0) {
         if (start < 0) start = k;
-        if (k != start + cnt || off + cnt >= MELW_MAX) {
-          set_error("mel filterbank: non-contiguous support or table overflow at filter %d", m);
+        if (k != start + cnt || cnt >= MEL_GROUP_TAPS[j]) {
+          set_error("mel filterbank: filter %d has a non-contiguous support or more than %d bins", m, MEL_GROUP_TAPS[j]);
           return CACO_ERR_INVALID;
         }
-        h->melw[off + cnt] = (float)wgt;
+        h->melw[(slot0[j] + cnt) * 16 + t] = (float)wgt;
         ++cnt;
       }
     }
-    h->mel_start[m] = start < 0 ? 0 : start;
-    h->mel_off[m] = off;
-    h->mel_cnt[m] = cnt;
-    off += cnt;
+    // zero-weight padding taps read bins start .. start + taps - 1: keep them inside the 257 magnitudes
+    if (start < 0) start = 0;                   // empty filter (HTK filter 0 at this resolution): all-zero weights
+    if (start + MEL_GROUP_TAPS[j] > NBIN) {
+      set_error("mel filterbank: padded taps of filter %d run past bin %d", m, NBIN - 1);
+      return CACO_ERR_INVALID;
+    }
+    h->mel_start[m] = start;
   }
   MelTables* d = nullptr;
   CACO_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(MelTables)));

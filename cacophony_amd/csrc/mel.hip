@@ -34,55 +34,60 @@ constexpr int MEL_GROUP_TAPS[NMEL / 16] = {2, 2, 2, 3, 4, 6, 8, 11};
 constexpr int MEL_TAPS = 2 + 2 + 2 + 3 + 4 + 6 + 8 + 11;
 
 struct MelTables {            // device image; the first LDS_FLOATS floats are staged into LDS verbatim
+  float tw512[512];           // e^{-2 pi i k / 512}, k = 0..255, interleaved re/im
   float tw256[512];           // e^{-2 pi i n1 k2 / 256}, index (n1*16 + k2) (symmetric), interleaved re/im
-  float tw512[512];           // e^{-2 pi i k / 512}, k = 0..255
   float hann512[NFFT];        // periodic Hann(400) centred in the 512-point frame, zeros outside
   float melw[MEL_TAPS * 16];  // [tap slot][t]: weight of thread t's filter t + 16 j at bin mel_start + i
   int mel_start[NMEL];        // first bin of filter m
 };
-constexpr int LDS_FLOATS = 1024;
+constexpr int LDS_FLOATS = 512;
 static_assert(sizeof(MelTables) % 16 == 0, "MelTables must be float4-copyable");
 
+typedef float c32 __attribute__((ext_vector_type(2)));
 constexpr int XP = 272;       // complex pitch per frame: 16*17, and 2*XP = 32 (mod 64) banks
 
 struct __attribute__((aligned(16))) MelSmem {
   float samp[SPAN];                 // samples, later the [16][128] log-mel tile
-  float tw256[512];
   float tw512[512];
-  float2 buf[FPB * XP];             // FFT transposition / spectrum, later magnitudes
+  c32 buf[FPB * XP];                // FFT transposition / spectrum, later magnitudes
 };
-static_assert(SPAN % 4 == 0 && SPAN >= FPB * NMEL, "sample span is float4-copyable and holds the log-mel tile");
+constexpr int TP = NMEL + 16;  // log-mel tile pitch
+static_assert(SPAN % 4 == 0 && SPAN >= FPB * TP, "sample span is float4-copyable and holds the log-mel tile");
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+// Complex numbers are native 2-vectors so that every complex add / multiply maps onto the packed fp32 VALU ops
+// (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32: two floats per lane per issue slot); the swaps and sign flips of conj and
+// multiply-by-i fold into the op_sel / neg modifiers of those instructions.
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {   // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+  const c32 bs = {-b.y, b.x};
+  return a.xx * b + a.yy * bs;
+}
+__device__ __forceinline__ c32 mul_mi(c32 a) { return (c32){a.y, -a.x}; }   // a * (-i)
 
 // forward 4-point DFT (W4 = -i)
-__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
-  const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = mul_mi(csub(x1, x3));
-  x0 = cadd(s02, s13);
-  x2 = csub(s02, s13);
-  x1 = cadd(d02, d13);
-  x3 = csub(d02, d13);
+__device__ __forceinline__ void dft4(c32& x0, c32& x1, c32& x2, c32& x3) {
+  const c32 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = mul_mi(x1 - x3);
+  x0 = s02 + s13;
+  x2 = s02 - s13;
+  x1 = d02 + d13;
+  x3 = d02 - d13;
 }
 
 // forward 16-point DFT in registers, natural order in and out (two radix-4 passes).
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+__device__ __forceinline__ void dft16(c32 (&v)[16]) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
   // pass 1: for each b, DFT4 over a of v[b + 4a]
 #pragma unroll
   for (int b = 0; b < 4; ++b) dft4(v[b], v[b + 4], v[b + 8], v[b + 12]);
   // now v[b + 4c] = y[b][c]; twiddle by W16^{b c}
-  v[1 + 4] = cmul(v[1 + 4], make_float2(C1, -S1));        // bc = 1
-  v[1 + 8] = cmul(v[1 + 8], make_float2(R2, -R2));        // 2
-  v[1 + 12] = cmul(v[1 + 12], make_float2(S1, -C1));      // 3
-  v[2 + 4] = cmul(v[2 + 4], make_float2(R2, -R2));        // 2
-  v[2 + 8] = mul_mi(v[2 + 8]);                            // 4
-  v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, -R2));     // 6
-  v[3 + 4] = cmul(v[3 + 4], make_float2(S1, -C1));        // 3
-  v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, -R2));       // 6
-  v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, S1));      // 9
+  v[1 + 4] = cmul(v[1 + 4], (c32){C1, -S1});        // bc = 1
+  v[1 + 8] = cmul(v[1 + 8], (c32){R2, -R2});        // 2
+  v[1 + 12] = cmul(v[1 + 12], (c32){S1, -C1});      // 3
+  v[2 + 4] = cmul(v[2 + 4], (c32){R2, -R2});        // 2
+  v[2 + 8] = mul_mi(v[2 + 8]);                      // 4
+  v[2 + 12] = cmul(v[2 + 12], (c32){-R2, -R2});     // 6
+  v[3 + 4] = cmul(v[3 + 4], (c32){S1, -C1});        // 3
+  v[3 + 8] = cmul(v[3 + 8], (c32){-R2, -R2});       // 6
+  v[3 + 12] = cmul(v[3 + 12], (c32){-C1, S1});      // 9
   // pass 2: for each c, DFT4 over b of y[b][c] -> X[c + 4d]
 #pragma unroll
   for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
@@ -91,7 +96,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int d = c + 1; d < 4; ++d) {
-      const float2 tmp = v[4 * c + d];
+      const c32 tmp = v[4 * c + d];
       v[4 * c + d] = v[4 * d + c];
       v[4 * d + c] = tmp;
     }
@@ -108,21 +113,56 @@ static_assert(sizeof(MelSmem) * 2 <= 160 * 1024, "two workgroups per CU");
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ wav, int64_t n_samples,
                                                   const MelTables* __restrict__ tables, void* __restrict__ out,
-                                                  int frames_out, int rows_out, int S, float scale, float bias, int nblk) {
+                                                  int frames_out, int rows_out, int S, float scale, float bias, int nblk,
+                                                  float* __restrict__ tinds, float* __restrict__ finds,
+                                                  float* __restrict__ mask, const int64_t* __restrict__ lengths) {
   __shared__ MelSmem sm;
   const int tid = threadIdx.x, fl = tid >> 4, t = tid & 15;
   const int b = blockIdx.y;
   const float* w = wav + (int64_t)b * n_samples;
+  if constexpr (MODE != MEL_NATURAL_F32) {
+    // ---- patch bookkeeping of spectrogram_to_patches (eval_caco_torch.py:132-144), done by the same launch --------------
+    // lengths != null: clip b holds lengths[b] real samples (the rest of its row is zero padding): its spectrogram has
+    // ceil(len / 160) frames and only the patches of those frames are valid - what the reference gets by running
+    // prepare_audio_batch (:181-206) clip by clip.  The mel values of the frames it does have are the same either way: the
+    // STFT pads with zeros (:78).  Rows [valid, S) of the patch tensor are zero, their indices 0, their mask 0.
+    constexpr int nfreq = NMEL / 16;
+    if (lengths) {
+      int64_t len = lengths[b];
+      len = len < 0 ? 0 : (len > n_samples ? n_samples : len);
+      const int64_t full_b = ((len + HOP - 1) / HOP / FPB) * nfreq;
+      if (full_b < rows_out) rows_out = (int)full_b;
+      const int nblk_b = (rows_out + nfreq - 1) / nfreq;
+      if (nblk_b < nblk) nblk = nblk_b;
+    }
+    for (int p = blockIdx.x * 256 + tid; p < S; p += gridDim.x * 256) {
+      const bool keep = p < rows_out;
+      const int q = keep ? p : 0;
+      if (tinds) tinds[(int64_t)b * S + p] = (float)(q / nfreq);
+      if (finds) finds[(int64_t)b * S + p] = (float)(q % nfreq);
+      if (mask) mask[(int64_t)b * S + p] = keep ? 1.f : 0.f;
+    }
+    for (int p = rows_out + blockIdx.x; p < S; p += gridDim.x) {
+      const int64_t o = ((int64_t)b * S + p) * 256 + tid;
+      if constexpr (MODE == MEL_PATCH_BF16) reinterpret_cast<bf16_t*>(out)[o] = (bf16_t)0.f;
+      else reinterpret_cast<float*>(out)[o] = 0.f;
+    }
+    if ((int)blockIdx.x >= nblk) return;      // nothing to transform (whole-workgroup exit: no barrier is skipped by a part)
+  }
 
   // ---- constant tables: staged ONCE per workgroup; the workgroup then walks several 16-frame blocks ----------
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(tables);
-    f32x4* dst = reinterpret_cast<f32x4*>(sm.tw256);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm.tw512);
     for (int i = tid; i < LDS_FLOATS / 4; i += 256) dst[i] = src[i];
   }
-  float2 hreg[14];                       // window taps of complex samples n = t + 16 n2, n2 = 1..14
+  c32 hreg[14];                          // window taps of complex samples n = t + 16 n2, n2 = 1..14
 #pragma unroll
-  for (int n2 = 1; n2 < 15; ++n2) hreg[n2 - 1] = *reinterpret_cast<const float2*>(&tables->hann512[2 * (t + 16 * n2)]);
+  for (int n2 = 1; n2 < 15; ++n2) hreg[n2 - 1] = *reinterpret_cast<const c32*>(&tables->hann512[2 * (t + 16 * n2)]);
+  // W256^(n1 k2) is symmetric in (n1, k2): fetched as [k2][n1 = t], consecutive lanes read consecutive words
+  c32 twreg[15];
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) twreg[k2 - 1] = *reinterpret_cast<const c32*>(&tables->tw256[2 * (k2 * 16 + t)]);
   float wreg[MEL_TAPS];
 #pragma unroll
   for (int i = 0; i < MEL_TAPS; ++i) wreg[i] = tables->melw[i * 16 + t];
@@ -131,50 +171,57 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
   for (int j = 0; j < NMEL / 16; ++j) mstart[j] = tables->mel_start[t + 16 * j];
   const bool vec_ok = (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(wav) & 15) == 0;
 
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int f0 = blk * FPB;
-    const int64_t g0 = (int64_t)f0 * HOP + SOFF;
-    __syncthreads();          // previous block's tile (aliases samp) fully stored; tables visible on the first pass
-    if (vec_ok) {
-      for (int i = tid; i < SPAN / 4; i += 256) {
+  // the 2848 samples of a block as 712 float4, <= 3 per thread: fetched into registers one block ahead, so the HBM
+  // latency of block i+1 hides under the transform of block i
+  auto fetch = [&](int blk_, f32x4 (&pf)[3]) {
+    const int64_t g0 = (int64_t)blk_ * (FPB * HOP) + SOFF;
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const int i = tid + 256 * r3;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < SPAN / 4) {
         const int64_t g = g0 + 4 * i;
-        f32x4 v;
-        if (g + 3 < n_samples) {
+        if (vec_ok && g + 3 < n_samples) {
           v = *reinterpret_cast<const f32x4*>(w + g);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (g + r < n_samples) ? w[g + r] : 0.f;   // zero pad, :78
         }
-        *reinterpret_cast<f32x4*>(&sm.samp[4 * i]) = v;
       }
-    } else {
-      for (int i = tid; i < SPAN; i += 256) sm.samp[i] = (g0 + i < n_samples) ? w[g0 + i] : 0.f;
+      pf[r3] = v;
+    }
+  };
+  f32x4 pf[3];
+  if ((int)blockIdx.x < nblk) fetch(blockIdx.x, pf);
+
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int f0 = blk * FPB;
+    __syncthreads();          // previous block's tile (aliases samp) fully stored; tables visible on the first pass
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const int i = tid + 256 * r3;
+      if (i < SPAN / 4) *reinterpret_cast<f32x4*>(&sm.samp[4 * i]) = pf[r3];
     }
     __syncthreads();
+    if (blk + (int)gridDim.x < nblk) fetch(blk + gridDim.x, pf);
 
     // From here to the tile write every exchange stays inside one frame = 16 lanes of ONE wave: LDS operations of a
     // wave execute in order, so wave-level ordering (no workgroup barrier) is enough between the passes.
     // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
-    float2 v[16];
+    c32 v[16];
     {
-      const float2* sp = reinterpret_cast<const float2*>(&sm.samp[fl * HOP - SOFF]) + t;   // complex sample n at sp[n - t]
-      v[0] = make_float2(0.f, 0.f);            // n < 16: real samples < 32, window zero
-      v[15] = make_float2(0.f, 0.f);           // n >= 240: real samples >= 480, window zero
+      const c32* sp = reinterpret_cast<const c32*>(&sm.samp[fl * HOP - SOFF]) + t;   // complex sample n at sp[n - t]
+      v[0] = (c32){0.f, 0.f};                  // n < 16: real samples < 32, window zero
+      v[15] = (c32){0.f, 0.f};                 // n >= 240: real samples >= 480, window zero
 #pragma unroll
-      for (int n2 = 1; n2 < 15; ++n2) {
-        const float2 x = sp[16 * n2];
-        v[n2] = make_float2(x.x * hreg[n2 - 1].x, x.y * hreg[n2 - 1].y);
-      }
+      for (int n2 = 1; n2 < 15; ++n2) v[n2] = sp[16 * n2] * hreg[n2 - 1];
     }
     dft16(v);
     {
-      // W256^(n1 k2) is symmetric in (n1, k2): read it as [k2][n1 = t] so that the 16 lanes of a frame fetch consecutive
-      // words (as [t][k2] the lane stride was 128 bytes: an 8-way bank conflict on every one of the 16 reads)
-      const float2* tw = reinterpret_cast<const float2*>(sm.tw256) + t;
-      float2* col = sm.buf + fl * XP + t * 17;
+      c32* col = sm.buf + fl * XP + t * 17;
       col[0] = v[0];                           // W^0
 #pragma unroll
-      for (int k2 = 1; k2 < 16; ++k2) col[k2] = cmul(v[k2], tw[k2 * 16]);
+      for (int k2 = 1; k2 < 16; ++k2) col[k2] = cmul(v[k2], twreg[k2 - 1]);
     }
     __builtin_amdgcn_wave_barrier();
     // ---- pass B: thread k2 = t transforms over n1 -> X[k2 + 16 k1] -----------------------------------
@@ -187,23 +234,23 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
     __builtin_amdgcn_wave_barrier();
 
     // ---- real-input split + magnitude: R[k] = ((Zk + conj Z-k) - i w^k (Zk - conj Z-k)) / 2 ----------
+    // (the factor 1/2 is folded into the filterbank weights: exact in binary floating point)
     float mag[16], mag256;
     {
-      const float2* X = sm.buf + fl * XP;
-      const float2* tw = reinterpret_cast<const float2*>(sm.tw512) + t;
+      const c32* X = sm.buf + fl * XP;
+      const c32* tw = reinterpret_cast<const c32*>(sm.tw512) + t;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int k = t + 16 * j;
-        const float2 zk = X[k];
-        const float2 zr = X[(256 - k) & 255];
-        const float2 zc = make_float2(zr.x, -zr.y);
-        const float2 e = cadd(zk, zc), d = csub(zk, zc);
-        const float2 wd = cmul(tw[16 * j], d);
-        const float re = 0.5f * (e.x + wd.y), im = 0.5f * (e.y - wd.x);   // e - i*wd
-        mag[j] = __builtin_amdgcn_sqrtf(re * re + im * im);
+        const c32 zk = X[k];
+        const c32 zr = X[(256 - k) & 255];
+        const c32 zc = {zr.x, -zr.y};
+        const c32 e = zk + zc, d = zk - zc;
+        const c32 r = e + mul_mi(cmul(tw[16 * j], d));       // 2 R[k] = e - i w^k d
+        mag[j] = __builtin_amdgcn_sqrtf(r.x * r.x + r.y * r.y);
       }
-      const float2 z0 = X[0];
-      mag256 = fabsf(z0.x - z0.y);             // R[256] = Re Z0 - Im Z0 (real)
+      const c32 z0 = X[0];
+      mag256 = 2.f * fabsf(z0.x - z0.y);       // 2 R[256] = 2 (Re Z0 - Im Z0) (real)
     }
     __builtin_amdgcn_wave_barrier();
     // inside this frame's own spectrum region (544 floats for 257 magnitudes); odd frames are shifted by 16 floats so that
@@ -229,9 +276,10 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
       }
     }
     __syncthreads();                            // every frame is done reading the samples: samp becomes the tile
-    float* tile = sm.samp;                      // [16 frames][128 mels]
+    float* tile = sm.samp;                      // [16 frames][TP]: pitch 144 = 16 (mod 64) banks keeps the two frames of a
+                                                // 32-lane write group and the 4 frames of a b128 read group on distinct banks
 #pragma unroll
-    for (int j = 0; j < NMEL / 16; ++j) tile[fl * NMEL + t + 16 * j] = melv[j];
+    for (int j = 0; j < NMEL / 16; ++j) tile[fl * TP + t + 16 * j] = melv[j];
     __syncthreads();
 
     // ---- coalesced 16/32-byte stores -----------------------------------------------------------------
@@ -240,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
       if (frame < frames_out) {
         const int m0 = (tid & 15) * 8;
         float* op = reinterpret_cast<float*>(out) + ((int64_t)b * frames_out + frame) * NMEL + m0;
-        const float* tp = tile + (tid >> 4) * NMEL + m0;
+        const float* tp = tile + (tid >> 4) * TP + m0;
         *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(tp);
         *reinterpret_cast<f32x4*>(op + 4) = *reinterpret_cast<const f32x4*>(tp + 4);
       }
@@ -249,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
       const int f = tid >> 5, rem = tid & 31, tt = rem >> 1, m0 = (rem & 1) * 8;
       const int p = blk * 8 + f;
       if (p < rows_out) {
-        const float* tp = tile + tt * NMEL + f * 16 + m0;
+        const float* tp = tile + tt * TP + f * 16 + m0;
         const int64_t o = ((int64_t)b * S + p) * 256 + tt * 16 + m0;
         if constexpr (MODE == MEL_PATCH_BF16) {
           bf16x8 pk;
@@ -263,39 +311,6 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
         }
       }
     }
-  }
-}
-
-// zero rows [valid, S) of the patch tensor and write time / freq indices and mask
-// (spectrogram_to_patches, eval_caco_torch.py:132-144).  lengths != null: clip b holds lengths[b] real samples (the rest of
-// its row is zero padding): its spectrogram has ceil(len / 160) frames and only the patches of those frames are valid -
-// what the reference gets by running prepare_audio_batch (:181-206) clip by clip.  The mel values of the frames it does
-// have are the same either way: the STFT pads with zeros (:78).
-template <typename T>
-__global__ void patch_meta_kernel(T* __restrict__ patches, float* __restrict__ tinds, float* __restrict__ finds,
-                                  float* __restrict__ mask, int S, int valid, int nfreq, const int64_t* __restrict__ lengths,
-                                  int64_t n_samples) {
-  const int b = blockIdx.y;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= S) return;
-  const int lane = threadIdx.x & 63;
-  int valid_b = valid;
-  if (lengths) {
-    int64_t len = lengths[b];
-    len = len < 0 ? 0 : (len > n_samples ? n_samples : len);
-    const int64_t full_b = ((len + HOP - 1) / HOP / FPB) * nfreq;
-    valid_b = full_b < valid ? (int)full_b : valid;
-  }
-  const bool keep = p < valid_b;
-  if (lane == 0) {
-    const int q = keep ? p : 0;
-    if (tinds) tinds[(int64_t)b * S + p] = (float)(q / nfreq);
-    if (finds) finds[(int64_t)b * S + p] = (float)(q % nfreq);
-    if (mask) mask[(int64_t)b * S + p] = keep ? 1.f : 0.f;
-  }
-  if (!keep) {
-    T* row = patches + ((int64_t)b * S + p) * 256;
-    for (int i = lane; i < 256; i += 64) row[i] = (T)0.f;
   }
 }
 
@@ -341,7 +356,7 @@ int ensure_tables(MelTables** out) {
           set_error("mel filterbank: filter %d has a non-contiguous support or more than %d bins", m, MEL_GROUP_TAPS[j]);
           return CACO_ERR_INVALID;
         }
-        h->melw[(slot0[j] + cnt) * 16 + t] = (float)wgt;
+        h->melw[(slot0[j] + cnt) * 16 + t] = 0.5f * (float)wgt;     // the kernel hands over 2 |R[k]|
         ++cnt;
       }
     }
@@ -382,7 +397,7 @@ int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches
     const int nblk = (frames + FPB - 1) / FPB;
     const dim3 grid(mel_grid_x(nblk, batch), batch);
     hipLaunchKernelGGL(mel_kernel<MEL_NATURAL_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, 0, 0,
-                       scale, bias, nblk);
+                       scale, bias, nblk, nullptr, nullptr, nullptr, nullptr);
     return check_hip(hipGetLastError(), "mel launch");
   }
   CACO_REQUIRE(max_patches > 0, "mel: max_patches must be positive");
@@ -390,28 +405,15 @@ int mel_frontend(const float* wav, int batch, int64_t n_samples, int max_patches
   const int full = n_tp * nfreq;
   const int valid = full < max_patches ? full : max_patches;   // truncation branch keeps the first max_patches
   const int blocks = (valid + nfreq - 1) / nfreq;
-  if (blocks > 0) {
-    const dim3 grid(mel_grid_x(blocks, batch), batch);
-    if (mode == MEL_PATCH_BF16)
-      hipLaunchKernelGGL(mel_kernel<MEL_PATCH_BF16>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
-                         max_patches, scale, bias, blocks);
-    else
-      hipLaunchKernelGGL(mel_kernel<MEL_PATCH_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
-                         max_patches, scale, bias, blocks);
-    rc = check_hip(hipGetLastError(), "mel patch launch");
-    if (rc) return rc;
-  }
-  if (valid < max_patches || tinds || finds || mask || lengths) {
-    const dim3 grid((max_patches + 3) / 4, batch);
-    if (mode == MEL_PATCH_BF16)
-      hipLaunchKernelGGL(patch_meta_kernel<bf16_t>, grid, dim3(256), 0, st, reinterpret_cast<bf16_t*>(out), tinds, finds,
-                         mask, max_patches, valid, nfreq, lengths, n_samples);
-    else
-      hipLaunchKernelGGL(patch_meta_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<float*>(out), tinds, finds, mask,
-                         max_patches, valid, nfreq, lengths, n_samples);
-    rc = check_hip(hipGetLastError(), "patch meta launch");
-  }
-  return rc;
+  // one launch: the transform blocks, the zero tail rows [valid, max_patches) and the index / mask arrays
+  const dim3 grid(mel_grid_x(blocks < 1 ? 1 : blocks, batch), batch);
+  if (mode == MEL_PATCH_BF16)
+    hipLaunchKernelGGL(mel_kernel<MEL_PATCH_BF16>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
+                       max_patches, scale, bias, blocks, tinds, finds, mask, lengths);
+  else
+    hipLaunchKernelGGL(mel_kernel<MEL_PATCH_F32>, grid, dim3(256), 0, st, wav, n_samples, g_tables, out, frames, valid,
+                       max_patches, scale, bias, blocks, tinds, finds, mask, lengths);
+  return check_hip(hipGetLastError(), "mel patch launch");
 }
 
 }  // namespace caco

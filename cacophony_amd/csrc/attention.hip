@@ -10,8 +10,11 @@
 // Q and K are k-contiguous MFMA operands as they are; V (key-major) is the transposed operand of P.V and is read
 // from LDS with the gfx950 hardware transpose read (ds_read_b64_tr_b16), so no V^T copy is ever written.
 //
-// Work split: one workgroup = NW waves = 32*NW query rows of one (clip, head); each wave owns 32 query rows and
-// the full head dimension.  K / V tiles of 64 keys go HBM/L2 -> LDS by 16-byte DMA (buffer_load ... lds: no staging
+// Work split: one workgroup = NW waves = 32*QR*NW query rows of one (clip, head); each wave owns QR blocks of 32 query
+// rows and the full head dimension.  Every K / V fragment read from LDS is 1 KiB per wave and feeds one 32-cycle MFMA
+// per query block: with QR = 1 the four SIMDs of a CU ask the LDS for exactly its 128 bytes/clock at full MFMA rate -
+// the kernel is LDS-bound by construction.  QR = 2 (long sequences) uses each fragment for two MFMAs: half the LDS
+// bytes per flop, 256 registers per wave, two workgroups (= two independent barrier domains) per CU.  K / V tiles of 64 keys go HBM/L2 -> LDS by 16-byte DMA (buffer_load ... lds: no staging
 // registers, no ds_write), double-buffered, the next tile's DMA issued before the current tile's MFMAs.  The LDS
 // images are lane-linear (a DMA constraint), i.e. unpadded 2*HD-byte rows: the V image is conflict-free as it is for
 // the transpose reads; the K image is made conflict-free for ds_read_b128 by XOR-ing the low two bits of the 16-byte
@@ -29,6 +32,8 @@
 // diagonal) is only executed for tiles that contain a masked key; the O rescale only when some row's max moved.
 // A query row whose keys are all masked yields 0 (the reference yields NaN there; it cannot happen with
 // right-padded inputs).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -55,11 +60,11 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
 }
 
 // (the body lives in a __device__ function: the buffer-descriptor builtins it uses are not visible to the host pass)
-template <int HD, bool CAUSAL, int NW>
+template <int HD, bool CAUSAL, int NW, int QR>
 __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, int q_ld, int Sq, const bf16_t* __restrict__ kv, int ld,
                                                int k_off, int v_off, const float* __restrict__ key_mask, int S, int heads,
                                                bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
-  constexpr int NT = NW * 64, QB = NW * 32;
+  constexpr int NT = NW * 64, QB = NW * 32 * QR;
   constexpr int RP = HD * 2;                   // K and V row pitch in LDS = the unpadded row (192 / 128 bytes)
   constexpr int VP = RP;
   constexpr int KCH = HD / 8;                  // 16-byte chunks per K / V row
@@ -73,7 +78,24 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
 
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // Workgroup -> (query block, head, clip).  The hardware deals workgroups to the 8 XCDs round-robin in linear order, and
+  // each XCD has its own L2.  All the workgroups of one clip read the same rows of the QKV buffer (a head's K / V slice is
+  // 192 bytes of a 4.6 KB row: neighbouring heads share cache lines, query blocks share whole tiles), so they are given
+  // consecutive slots of ONE XCD: clip b lives on XCD b % 8 and its rows cross the fabric once (round 2 counters: 91 % L2
+  // misses and 1.3 GB fetched per launch for a 0.59 GB buffer with the plain mapping).
+  int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  {
+    const int per_clip = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int b8 = (gridDim.z / 8) * 8;                // clips covered by the remap (the tail keeps the plain order)
+    if (lin < per_clip * b8) {
+      const int xcd = lin & 7, slot = lin >> 3;
+      const int w = slot % per_clip;
+      b = (slot / per_clip) * 8 + xcd;
+      qb = w % gridDim.x;
+      h = w / gridDim.x;
+    }
+  }
   const int H = heads * HD;
   // queries: rows [b*Sq, b*Sq+Sq) of qp_ (row stride q_ld); keys / values: rows [b*S, b*S+S) of kv (row stride ld), at
   // columns k_off / v_off past the head's first column.  Self-attention passes the same buffer twice (Sq == S).
@@ -81,16 +103,17 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   const bf16_t* q_base = qp_ + qrow_base * q_ld + h * HD;
   const bf16_t* kv_base = kv + (int64_t)b * kv_rows * ld + h * HD;    // kv_rows >= S: rows between two clips' keys (a KV cache)
 
-  const int q0 = qb * QB + wave * 32;
-  const int q_row = q0 + l31;
+  const int q0 = qb * QB + wave * (32 * QR);     // query block x of this wave: rows q0 + 32 x + l31
   const bool wave_active = q0 < Sq;
 
   // Q fragments (B operand: column j = query, k = 8 contiguous head-dim elements)
-  bf16x8 qf[KS];
-  {
+  bf16x8 qf[QR][KS];
+#pragma unroll
+  for (int x = 0; x < QR; ++x) {
+    const int q_row = q0 + 32 * x + l31;
     const bf16_t* qp = q_base + (int64_t)(q_row < Sq ? q_row : Sq - 1) * q_ld + hf * 8;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    for (int ks = 0; ks < KS; ++ks) qf[x][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
   }
 
   int ntiles = (S + KT - 1) / KT;
@@ -141,12 +164,16 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
     }
   };
 
-  f32x16 o[DT];
+  f32x16 o[QR][DT];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+  for (int x = 0; x < QR; ++x)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;     // running max of the RAW scores, running sum of exp
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][dt][r] = 0.f;
+  float m_run[QR], l_run[QR];               // running max of the RAW scores, running sum of exp
+#pragma unroll
+  for (int x = 0; x < QR; ++x) { m_run[x] = -INFINITY; l_run[x] = 0.f; }
 
   // per-lane part of the transposed V fragment address: 16-lane group (lane >> 4) & 1 selects the 16-column half,
   // lane >> 5 the 8-key half, (lane & 15) >> 2 the key within a 4-key block, lane & 3 the 4-column piece
@@ -163,9 +190,10 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       const char* kb = smem + (t & 1) * BUF;
       const char* vb = kb + K_BYTES;
       const float* bias = reinterpret_cast<const float*>(vb + V_BYTES);
-      f32x16 s[2];
+      f32x16 s[QR][2];
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      // the two 32-key chains are interleaved so that no MFMA waits on the one issued right before it
+      // the 2 QR chains (32-key halves x query blocks) are interleaved so that no MFMA waits on the one issued right
+      // before it; each K fragment is read once and used by every query block
       const int kx = (key_perm(l31) >> 2) & 3;          // same for both 32-key halves (32 >> 2 is a multiple of 4)
       const char* kr = kb + key_perm(l31) * RP;
 #pragma unroll
@@ -175,73 +203,80 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + st * 32 * RP + coff);
-          s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[st], 0, 0, 0);   // C = 0 literal
+#pragma unroll
+          for (int x = 0; x < QR; ++x)
+            s[x][st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[x][ks], ks == 0 ? zero16 : s[x][st], 0, 0, 0);   // C = 0 literal
         }
       }
-      // masks (only for tiles that have any): s[st][g*8 + e] is key t*64 + st*32 + 16*g + 8*hf + e
       const bool pad_tile = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(bias + KT)[0]) != 0;
       const bool diag_tile = CAUSAL && (t * KT + KT - 1 > q0);
-      if (pad_tile || diag_tile) {
+      bf16x8 pf[QR][4];
+#pragma unroll
+      for (int x = 0; x < QR; ++x) {
+        const int q_row = q0 + 32 * x + l31;
+        // masks (only for tiles that have any): s[x][st][g*8 + e] is key t*64 + st*32 + 16*g + 8*hf + e
+        if (pad_tile || diag_tile) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int kl = st * 32 + 16 * g + 8 * hf;
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + kl);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + kl + 4);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float v = s[x][st][g * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
+                if (CAUSAL && (t * KT + kl + e) > q_row) v = -INFINITY;
+                s[x][st][g * 8 + e] = v;
+              }
+            }
+        }
+        float m_tile = -INFINITY;
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const int kl = st * 32 + 16 * g + 8 * hf;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + kl);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + kl + 4);
+          for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[x][st][r]);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run[x], m_tile);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float neg = -m_use * scale_log2;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 work on register pairs) and four independent partial sums
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {scale_log2, scale_log2}, neg2 = {neg, neg};
+        f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float v = s[st][g * 8 + e] + (e < 4 ? b0[e] : b1[e - 4]);
-              if (CAUSAL && (t * KT + kl + e) > q_row) v = -INFINITY;
-              s[st][g * 8 + e] = v;
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const f32x2 sv = {s[x][st][g * 8 + e], s[x][st][g * 8 + e + 1]};
+              const f32x2 xx = __builtin_elementwise_fma(sv, sc2, neg2);
+              const f32x2 p = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+              ps2[(e >> 1) & 1] += p;
+              pf[x][st * 2 + g][e] = (bf16_t)p[0];
+              pf[x][st * 2 + g][e + 1] = (bf16_t)p[1];
             }
-          }
+        const float psum = (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
+        if (__ballot(m_new > m_run[x]) != 0ull) {       // some row's max moved: rescale this block's running state
+          const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_use) * scale_log2);   // m_run = -inf -> 0
+          l_run[x] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[x][dt][r] *= alpha;
+          m_run[x] = m_new;
+        }
+        l_run[x] += psum;
       }
-      float m_tile = -INFINITY;
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[st][r]);
-      m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-      const float m_new = fmaxf(m_run, m_tile);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float neg = -m_use * scale_log2;
-      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 work on register pairs) and four independent partial sums
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const f32x2 sc2 = {scale_log2, scale_log2}, neg2 = {neg, neg};
-      f32x2 ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-      bf16x8 pf[4];
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const f32x2 sv = {s[st][g * 8 + e], s[st][g * 8 + e + 1]};
-            const f32x2 x = __builtin_elementwise_fma(sv, sc2, neg2);
-            const f32x2 p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-            ps2[(e >> 1) & 1] += p;
-            pf[st * 2 + g][e] = (bf16_t)p[0];
-            pf[st * 2 + g][e + 1] = (bf16_t)p[1];
-          }
-      const float psum = (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
-      if (__ballot(m_new > m_run) != 0ull) {       // some row's max moved: rescale this wave's running state
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * scale_log2);   // m_run = -inf -> 0
-        l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += psum;
-      // O^T += V^T P^T
+      // O^T += V^T P^T: each transposed V fragment is read once and used by every query block
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {      // DT independent accumulator chains, interleaved
+        for (int dt = 0; dt < DT; ++dt) {      // QR * DT independent accumulator chains, interleaved
           const bf16x8 vf = v_frag_tr<VP>(vb + v_lane + dt * 64 + sp * 16 * VP);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], o[dt], 0, 0, 0);
+#pragma unroll
+          for (int x = 0; x < QR; ++x) o[x][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[x][sp], o[x][dt], 0, 0, 0);
         }
     }
     if (t + 1 < ntiles) finish_tile((t + 1) & 1);
@@ -250,62 +285,57 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   }
 
   if (!wave_active) return;
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-#ifdef ATTN_DIRECT_STORE
-  if (q_row < Sq) {        // 8-byte pieces at a row stride: 32 lines per store instruction (measured 57 of 405 us)
-    bf16_t* op = out + (qrow_base + q_row) * H + h * HD + 4 * hf;
+  // The output leaves as whole rows: a 32 x HD block is staged in LDS (the K / V ring is dead: the loop's last barrier is
+  // behind every wave; the region is wave-private) and stored 16 bytes per lane, consecutive lanes on consecutive chunks
+  // of a row.  Lane (l31, hf) holds query row l31, columns dt*32 + g*8 + 4*hf .. +3; the staging pitch RP + 16 keeps the
+  // 8-byte writes conflict-free.  (Direct 8-byte stores at a row stride cost 32 lines per instruction: 57 of 405 us.)
+  constexpr int OPITCH = RP + 16;
+  static_assert(NW * 32 * OPITCH <= 2 * BUF, "output staging must fit in the K / V ring");
+  char* stage = smem + wave * (32 * OPITCH);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int x = 0; x < QR; ++x) {
+    const int qx = q0 + 32 * x;
+    if (qx >= Sq) break;
+    const float l_tot = l_run[x] + __shfl_xor(l_run[x], 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
-        *reinterpret_cast<bf16x4*>(op + dt * 32 + g * 8) = v;
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[x][dt][g * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(stage + l31 * OPITCH + (dt * 32 + g * 8 + 4 * hf) * 2) = v;
       }
-  }
-#else
-  // The output leaves as whole rows: this wave's 32 x HD block is staged in LDS (the K / V ring is dead: the loop's
-  // last barrier is behind every wave; the region is wave-private) and stored 16 bytes per lane, consecutive lanes on
-  // consecutive chunks of a row.  Lane (l31, hf) holds query row l31, columns dt*32 + g*8 + 4*hf .. +3; the staging
-  // pitch RP + 16 keeps the 8-byte writes conflict-free.
-  constexpr int OPITCH = RP + 16;
-  static_assert(NW * 32 * OPITCH <= 2 * BUF, "output staging must fit in the K / V ring");
-  char* stage = smem + wave * (32 * OPITCH);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rows_valid = min(32, Sq - qx);
+    const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
+        out + (qrow_base + qx) * H + h * HD, 0, (rows_valid - 1) * H * 2 + RP, 0x00020000);    // rows past Sq fall outside
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
-      *reinterpret_cast<bf16x4*>(stage + l31 * OPITCH + (dt * 32 + g * 8 + 4 * hf) * 2) = v;
+    for (int it = 0; it < KCH / 2; ++it) {                   // 32 rows x KCH chunks of 16 B = KCH / 2 wave instructions
+      const int L = it * 64 + lane;
+      const int r = L / KCH, c = L % KCH;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * OPITCH + c * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, 0);
     }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int rows_valid = min(32, Sq - q0);
-  const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
-      out + (qrow_base + q0) * H + h * HD, 0, (rows_valid - 1) * H * 2 + RP, 0x00020000);    // rows past Sq fall outside
-#pragma unroll
-  for (int it = 0; it < KCH / 2; ++it) {                   // 32 rows x KCH chunks of 16 B = KCH / 2 wave instructions
-    const int L = it * 64 + lane;
-    const int r = L / KCH, c = L % KCH;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * OPITCH + c * 16);
-    __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging block is reused by the next query block
   }
-#endif
 }
 
-#ifndef ATTN_OCC
-#define ATTN_OCC 3          // workgroups per CU the register budget is held to (164 VGPRs)
-#endif
-template <int HD, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, ATTN_OCC) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
+// workgroups per CU the register budget is held to: 3 (164 VGPRs) with one query block per wave, 2 (256) with two
+template <int HD, bool CAUSAL, int NW, int QR>
+__global__ __launch_bounds__(NW * 64, QR == 1 ? 3 : 2) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
                                                                bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
-  attention_body<HD, CAUSAL, NW>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows);
+  attention_body<HD, CAUSAL, NW, QR>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows);
+}
+
+// experiment switch: CACO_ATTN_ROWS=32 keeps one query block per wave at every sequence length
+int attention_rows_per_wave() {
+  static const int v = [] { const char* e = getenv("CACO_ATTN_ROWS"); return e ? atoi(e) : 64; }();
+  return v;
 }
 
 }  // namespace
@@ -330,14 +360,19 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
   constexpr int NW = 4;
-  const dim3 grid((seq_q + NW * 32 - 1) / (NW * 32), heads, batch);
-#define CACO_ATTN(HD_, C_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows)
+  // two query blocks per wave once the sequence fills the 256-row workgroups that makes; short sequences (text, decoder)
+  // keep 128-row workgroups
+  const int qr = (seq_q > 128 && attention_rows_per_wave() != 32) ? 2 : 1;
+  const dim3 grid((seq_q + NW * 32 * qr - 1) / (NW * 32 * qr), heads, batch);
+#define CACO_ATTN(HD_, C_, QR_) \
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows)
+#define CACO_ATTN_QR(HD_, C_) do { if (qr == 2) CACO_ATTN(HD_, C_, 2); else CACO_ATTN(HD_, C_, 1); } while (0)
   if (head_dim == 96) {
-    if (causal) CACO_ATTN(96, true); else CACO_ATTN(96, false);
+    if (causal) CACO_ATTN_QR(96, true); else CACO_ATTN_QR(96, false);
   } else {
-    if (causal) CACO_ATTN(64, true); else CACO_ATTN(64, false);
+    if (causal) CACO_ATTN_QR(64, true); else CACO_ATTN_QR(64, false);
   }
+#undef CACO_ATTN_QR
 #undef CACO_ATTN
   return check_hip(hipGetLastError(), "attention launch");
 }

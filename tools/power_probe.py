@@ -83,15 +83,36 @@ def stages(seconds):
     measure("layernorm", lambda: lib.caco_op_layernorm(p(x), p(g), p(g), B * S, H, 1e-5, None, p(ob), st), seconds)
 
 
+def attn(seconds):
+    """The audio attention launch on random and on zero operands (same instruction stream)."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, S, heads, hd = 256, 496, 8, 96
+    H = heads * hd
+    km = torch.ones(B, S, device=dev)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
+    for data in ("randn", "zeros"):
+        qkv = torch.randn(B * S, 2560, device=dev).bfloat16()
+        if data == "zeros":
+            qkv.zero_()
+        measure(f"attention S=496 {data}", lambda: lib.caco_op_attention(p(qkv), 2560, H, 2 * H, p(km), B, S, heads, hd, 0, p(out), st),
+                seconds, flops=2 * 2 * S * S * H * B)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stages", action="store_true")
+    ap.add_argument("--attn", action="store_true")
     ap.add_argument("--only", default="fc1")
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=3.0)
     a = ap.parse_args()
     if a.stages:
         return stages(a.seconds)
+    if a.attn:
+        return attn(a.seconds)
     lib = _lib.load()
     lib.caco_set_gemm_tile(a.tile)
     dev = "cuda:0"

@@ -236,9 +236,27 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
         for (int st = 0; st < 2; ++st)
 #pragma unroll
           for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[x][st][r]);
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-        const float m_new = fmaxf(m_run[x], m_tile);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        {   // a row's 64 keys sit in lanes l and l + 32: one v_permlane32_swap joins the halves (no LDS round trip)
+          const unsigned mu = __builtin_bit_cast(unsigned, m_tile);
+          const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+          m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        // Lazy exponent reference: softmax is invariant to the reference point, so m_run only moves when the row max
+        // outgrows it by more than 2^8 (P <= 256 meanwhile; fp32 sums and bf16 P keep their relative precision).  The
+        // O rescale (24 packed multiplies per block) then runs about once per row block instead of once per tile.
+        const bool grow = (m_tile - m_run[x]) * scale_log2 > 8.f;     // m_run = -inf: true unless the tile is all masked
+        if (__ballot(grow) != 0ull) {
+          const float m_new = grow ? m_tile : m_run[x];
+          const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_new) * scale_log2);   // 1 for rows that keep theirs
+          const float a = (m_run[x] == -INFINITY) ? 0.f : alpha;      // -inf - -inf
+          l_run[x] *= a;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[x][dt][r] *= a;
+          m_run[x] = m_new;
+        }
+        const float m_use = (m_run[x] == -INFINITY) ? 0.f : m_run[x];
         const float neg = -m_use * scale_log2;
         // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32 work on register pairs) and four independent partial sums
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -257,17 +275,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
               pf[x][st * 2 + g][e] = (bf16_t)p[0];
               pf[x][st * 2 + g][e + 1] = (bf16_t)p[1];
             }
-        const float psum = (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
-        if (__ballot(m_new > m_run[x]) != 0ull) {       // some row's max moved: rescale this block's running state
-          const float alpha = __builtin_amdgcn_exp2f((m_run[x] - m_use) * scale_log2);   // m_run = -inf -> 0
-          l_run[x] *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[x][dt][r] *= alpha;
-          m_run[x] = m_new;
-        }
-        l_run[x] += psum;
+        l_run[x] += (ps2[0][0] + ps2[0][1]) + (ps2[1][0] + ps2[1][1]);
       }
       // O^T += V^T P^T: each transposed V fragment is read once and used by every query block
 #pragma unroll
@@ -362,15 +370,15 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   constexpr int NW = 4;
   // two query blocks per wave once the sequence fills the 256-row workgroups that makes; short sequences (text, decoder)
   // keep 128-row workgroups
-  const int qr = (seq_q > 128 && attention_rows_per_wave() != 32) ? 2 : 1;
+  const int qr = (!causal && seq_q > 128 && attention_rows_per_wave() != 32) ? 2 : 1;
   const dim3 grid((seq_q + NW * 32 * qr - 1) / (NW * 32 * qr), heads, batch);
 #define CACO_ATTN(HD_, C_, QR_) \
   hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows)
 #define CACO_ATTN_QR(HD_, C_) do { if (qr == 2) CACO_ATTN(HD_, C_, 2); else CACO_ATTN(HD_, C_, 1); } while (0)
   if (head_dim == 96) {
-    if (causal) CACO_ATTN_QR(96, true); else CACO_ATTN_QR(96, false);
+    if (causal) CACO_ATTN(96, true, 1); else CACO_ATTN_QR(96, false);
   } else {
-    if (causal) CACO_ATTN_QR(64, true); else CACO_ATTN_QR(64, false);
+    if (causal) CACO_ATTN(64, true, 1); else CACO_ATTN_QR(64, false);
   }
 #undef CACO_ATTN_QR
 #undef CACO_ATTN

@@ -244,6 +244,32 @@ def test_attention_forced_rescale(lib):
     assert (out[0, 7, :hd].float() - v[0, 450, :hd].float()).abs().max().item() < 0.05
 
 
+@pytest.mark.parametrize("slope", [0.5, 3.0])
+def test_attention_lazy_reference_ramp(lib, slope):
+    """Scores that climb steadily with the key index: the lazy exponent reference (attention.hip: it only moves when a row
+    maximum outgrows it by more than 2^8) is carried with P up to 256 through many tiles (slope 0.5: the reference never
+    moves after the first tile; slope 3: it moves every few tiles), for the one- and the two-block-per-wave kernels."""
+    B, S, heads, hd = 2, 500, 8, 96
+    H = heads * hd
+    qk = _rand((B, S, 2 * H), 40, 0.3)
+    u = torch.zeros(hd, device=DEV)
+    u[0] = 1.0
+    qk[:, :, :hd] += 4.0 * u                                            # every query of head 0 has a component along u ...
+    ramp = torch.arange(S, device=DEV, dtype=torch.float32) / 64.0      # ... and key k carries slope * (k / 64) of it:
+    qk[:, :, H:H + hd] += (slope * ramp)[None, :, None] * u * (math.sqrt(hd) * math.log(2.0) / 4.0)   # +slope in log2 units per tile
+    qk = qk.bfloat16()
+    v = _rand((B, S, H), 41).bfloat16()
+    qkv = torch.cat([qk, v], -1).contiguous()
+    ref = _attention_ref(qk, v, None, heads, hd, False)
+    for Sq in (S, 100):                                                 # 100 query rows: the one-block-per-wave kernel
+        out = torch.empty(B, Sq, H, dtype=torch.bfloat16, device=DEV)
+        q = qkv[:, :Sq, :H].contiguous()
+        _lib.check(lib.caco_op_attention_qkv(_p(q), H, Sq, _p(qkv), 3 * H, H, 2 * H, None, B, S, heads, hd, 0, _p(out), _st()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - ref[:, :Sq]).abs().max().item() < 0.03, (slope, Sq)
+
+
 # ------------------------------------------------------------------ front end vs oracle and reference goldens
 def test_mel_spectrogram_matches_reference_golden():
     g = load_golden("mel.npz")

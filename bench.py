@@ -160,13 +160,36 @@ def _cpu_baseline(state, budget_s: float = 45.0):
         torch.set_num_threads(best)
         stages = {}
         run(stages)
+        # the optional larger point of BASELINE.md 2: batch 32 feeds more threads than batch 4 does (one warm-up + one timed
+        # run per thread count, ~2-4 s each)
+        b32 = {}
+        b_big = 32
+        wav4, ids4, mask4 = wav, ids, mask
+        wav = synth.make_waveforms(b_big, N_SAMPLES, start=200)
+        ids, mask = synth.make_captions(b_big, TEXT_LEN)
+        for th in sorted({t for t in (best, 2 * best, 64) if t <= ncores}):
+            if time.time() - t_start > budget_s * 1.6:
+                break
+            torch.set_num_threads(th)
+            run()
+            t0 = time.perf_counter()
+            run()
+            b32[th] = time.perf_counter() - t0
+        wav, ids, mask = wav4, ids4, mask4
     finally:
         torch.set_num_threads(default_threads)
-    out = {"value": round(b / results[best], 3), "unit": "pairs/s", "cores": int(best), "kind": "port",
-           "sample": f"batch {b} x 10 s clips + {TEXT_LEN}-token captions, full 12+12-layer model, oracle torch-CPU backend, "
-                     f"median of 3 runs per thread count ({results[best] * 1e3:.0f} ms per batch at {best} threads)",
+    value, cores, sample_b, per_batch = b / results[best], best, b, results[best]
+    if b32:
+        th32 = min(b32, key=lambda t: b32[t])
+        if b_big / b32[th32] > value:
+            value, cores, sample_b, per_batch = b_big / b32[th32], th32, b_big, b32[th32]
+    out = {"value": round(value, 3), "unit": "pairs/s", "cores": int(cores), "kind": "port",
+           "sample": f"batch {sample_b} x 10 s clips + {TEXT_LEN}-token captions, full 12+12-layer model, oracle torch-CPU backend "
+                     f"({per_batch * 1e3:.0f} ms per batch at {cores} threads); best of a thread sweep at batch 4 (median of 3 runs "
+                     f"per thread count) and at batch 32 (one run per thread count)",
            "cpu_model": _cpu_model(), "host_cores": int(ncores),
            "thread_sweep_pairs_per_s": {str(t): round(b / v, 3) for t, v in sorted(results.items())},
+           "batch32_thread_sweep_pairs_per_s": {str(t): round(b_big / v, 3) for t, v in sorted(b32.items())},
            "stages_ms_at_best": {k: round(v, 1) for k, v in stages.items()}}
     if 1 in results:
         out["one_thread_pairs_per_s"] = round(b / results[1], 3)

@@ -347,7 +347,7 @@ def main():
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],
                         "note": "peak = nominal 2.4 GHz dense figure.  On random operands this kernel is power-limited: the same "
                                 "instruction stream runs 1.42 PFLOP/s at 2.38 GHz on zero operands vs 1.03 at 1.80 GHz at the 1400 W cap (profiles/r2_v2/power_probe.txt), and moving its epilogue under the K-loop "
-                                "(gemm_s8.hip: -15 % cycles per tile) returned as a lower clock, not as time (DESIGN.md 4.1)"}
+                                "(tools/experimental/gemm_s8.hip: -15 % cycles per tile) returned as a lower clock, not as time (DESIGN.md 4.1)"}
 
         if not args.no_extra_configs:
             extra = {}

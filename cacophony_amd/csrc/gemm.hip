@@ -186,13 +186,11 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
     CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16: LayerNorm folding needs N %% 256 == 0 and K %% 64 == 0");
     return gemm_bf16_w8(p, epi, act, st);
   }
-  // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 6256 = w8 with the epilogue under its own K-loop
-  // (gemm_s8.hip: measured a draw), 2256 = 256x128 two workgroups per CU
+  // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 2256 = 256x128 two workgroups per CU
   if (cfg == 8256 && gemm_bf16_w8_ok(p, epi)) return gemm_bf16_w8(p, epi, act, st);
-  if (cfg == 6256 && gemm_bf16_s8_ok(p, epi)) return gemm_bf16_s8(p, epi, act, st);
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
   if (cfg == 256) {
-    // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w4.hip: most reuse per L2 byte) when every
+    // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w8.hip: most reuse per L2 byte) when every
     // CU gets >= 2 tiles, else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128.
     // Threshold in 256x128-tile units.  128 also sends the text tower's M = 8192 GEMMs to w8: in isolation the 128x128
     // kernel is faster for its N = 768 shapes, but the text tower runs NEXT TO the audio tower and a few persistent
@@ -215,7 +213,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256 || tile == 6256) g_tile_cfg = tile;   // > 256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256) g_tile_cfg = tile;   // > 256: force a kernel
   return gemm_tile_config();
 }
 

@@ -47,8 +47,6 @@ int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w8_ok(const GemmArgs& p, int epi);                         // gemm_w8.hip: persistent 256x256, the default
 int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st);
-bool gemm_bf16_s8_ok(const GemmArgs& p, int epi);                         // gemm_s8.hip: w8 with the epilogue under its K-loop
-int gemm_bf16_s8(const GemmArgs& p, int epi, int act, hipStream_t st);
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
              hipStream_t st, int lda = 0, int ldb = 0);     // lda / ldb: row strides of A / B in elements (0 = K)
 

@@ -83,7 +83,7 @@ def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [256, 8256, 6256])
+@pytest.mark.parametrize("tile", [256, 8256])
 @pytest.mark.parametrize("M,N,K,kind", [(70000, 768, 768, "f32r"), (33333, 768, 3072, "f32r"), (50000, 2304, 768, "bf16"),
                                         (45000, 3072, 768, "silu")])
 def test_gemm_persistent_multi_tile_pipeline(lib, tile, M, N, K, kind):
@@ -112,31 +112,6 @@ def test_gemm_persistent_multi_tile_pipeline(lib, tile, M, N, K, kind):
             r = torch.nn.functional.silu(ref) if act else ref
             err = ((out.float() - r).abs() / (r.abs() + 1.0)).max().item()
             assert err < 2e-2, f"rep {rep}: max rel err {err}"
-    lib.caco_set_gemm_tile(256)
-
-
-@pytest.mark.parametrize("M,N,K,act", [(25600, 3072, 768, 1), (25600, 2304, 768, 0), (12032, 3072, 768, 1), (46080, 768, 3072, 0),
-                                       (126976, 3072, 768, 1), (15360, 2304, 512, 1)])
-def test_gemm_skewed_row_groups(lib, M, N, K, act):
-    """gemm_s8.hip (epilogue under the K-loop: row groups with K-ranges rotated across panel periods, one n-tile per
-    workgroup).  Every element, three repetitions (a stale-LDS race or a wrong panel selector shows as wrong row groups);
-    shapes with 1-6 panels per team, teams with unequal panel counts, the first / last period's idle groups."""
-    assert lib.caco_set_gemm_tile(6256) == 6256
-    a = _rand((M, K), 21).bfloat16()
-    w = _rand((N, K), 22, 1.0 / math.sqrt(K)).bfloat16()
-    bias = _rand((N,), 23)
-    ref = a.float() @ w.float().T + bias
-    if act == 1:
-        ref = torch.nn.functional.silu(ref)
-    for rep in range(3):
-        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        _lib.check(lib.caco_op_gemm_bf16(_p(a), _p(w), _p(bias), M, N, K, act, _p(out), _st()))
-        torch.cuda.synchronize()
-        assert torch.isfinite(out.float()).all(), f"rep {rep}: {(~torch.isfinite(out.float())).sum().item()} non-finite"
-        err = (out.float() - ref).abs()
-        tol = 2.0 ** -8 * ref.abs() + 2e-3
-        bad = err > tol
-        assert not bad.any(), f"rep {rep}: {bad.sum().item()} bad, first at {bad.nonzero()[0].tolist()}, max err {err.max().item():.4g}"
     lib.caco_set_gemm_tile(256)
 
 

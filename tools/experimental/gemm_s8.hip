@@ -1,3 +1,9 @@
+// NOT BUILT since the end of round 2 (the product ships what wins).  To try it again: copy this file back
+// to cacophony_amd/csrc/, add it to SOURCES in cacophony_amd/build.py, declare gemm_bf16_s8_ok / gemm_bf16_s8 in kernels.h
+// and give launch_epi (gemm.hip) a forced mode for it; tools/experimental/s8_timing.py reads its -DS8_TIMING stamps.
+// Its test (every element, three repetitions, 1-6 panels per team) was tests/test_gpu_ops.py::test_gemm_skewed_row_groups
+// at commit 354541b.
+//
 // gemm_bf16_s8: 256x256x64 bf16 MFMA GEMM whose epilogue runs UNDER ITS OWN K-LOOP ("skewed row groups").
 //   out[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
 //
@@ -26,7 +32,7 @@
 // read + DMA piece + scalar bookkeeping fill the ~64 cycles a wave has per MFMA of its own with two waves per SIMD), and the
 // two waves of a SIMD run the same slot at the same time, so every filler instruction adds its issue time to the K-tile
 // (ablations: each of parking copies / activation / read-back / stores added 1:1); the epilogue can be moved under the
-// K-loop but not made free.  Kept as an opt-in kernel and as the measurement behind DESIGN.md 4.1.
+// K-loop but not made free.  Kept as the measurement behind DESIGN.md 4.1; at the 1400 W power cap the saved cycles come back as a lower clock (power_probe: 587 vs 592 us at 1.68 vs 1.75 GHz).
 //
 //   waves     8 = 2 (M) x 4 (N), wave tile 128 x 64, two per SIMD
 //   LDS       A ring 2 x 32 KiB, W ring 2 x 32 KiB, 8 slabs x 4 KiB = 160 KiB; lane-linear images, bank swizzle

@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cacophony_amd import _lib  # noqa: E402
 
 SHAPES = {"qkv": (126976, 2304, 768, 0), "fc1": (126976, 3072, 768, 1)}

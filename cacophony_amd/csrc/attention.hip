@@ -13,12 +13,14 @@
 // Work split: one workgroup = NW waves = 32*QR*NW query rows of one (clip, head); each wave owns QR blocks of 32 query
 // rows and the full head dimension.  Every K / V fragment read from LDS is 1 KiB per wave and feeds one 32-cycle MFMA
 // per query block: with QR = 1 the four SIMDs of a CU ask the LDS for exactly its 128 bytes/clock at full MFMA rate -
-// the kernel is LDS-bound by construction.  QR = 2 (long sequences) uses each fragment for two MFMAs: half the LDS
-// bytes per flop, 256 registers per wave, two workgroups (= two independent barrier domains) per CU.  K / V tiles of 64 keys go HBM/L2 -> LDS by 16-byte DMA (buffer_load ... lds: no staging
-// registers, no ds_write), double-buffered, the next tile's DMA issued before the current tile's MFMAs.  The LDS
-// images are lane-linear (a DMA constraint), i.e. unpadded 2*HD-byte rows: the V image is conflict-free as it is for
-// the transpose reads; the K image is made conflict-free for ds_read_b128 by XOR-ing the low two bits of the 16-byte
-// chunk index with (key >> 2) & 3 on the SOURCE address and again on the read address.
+// the kernel is LDS-bound by construction.  QR = 2 (non-causal sequences longer than 128 rows: the audio encoder) uses
+// each fragment for two MFMAs: half the LDS bytes per flop, 256 registers per wave, two workgroups (= two independent
+// barrier domains) per CU.  QR = 1 (text, caption decoder): 164 registers, three workgroups per CU.
+// K / V tiles of 64 keys go HBM/L2 -> LDS by 16-byte DMA (buffer_load ... lds: no staging registers, no ds_write),
+// double-buffered, the next tile's DMA issued before the current tile's MFMAs.  The LDS images are lane-linear (a DMA
+// constraint), i.e. unpadded 2*HD-byte rows: the V image is conflict-free as it is for the transpose reads; the K image
+// is made conflict-free for ds_read_b128 by XOR-ing the low two bits of the 16-byte chunk index with (key >> 2) & 3 on
+// the SOURCE address and again on the read address.
 //
 // Math per 64-key tile, all on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
 //   S^T[key, q] = K Q^T      (operands swapped so that every lane owns ONE query column: the row-wise softmax is
@@ -27,9 +29,11 @@
 // The MFMA row <-> key assignment of the first product is permuted (bits 2 and 3 swapped) so that the S^T
 // accumulator registers of a lane are, in order, exactly the 8-key groups the P operand of the second MFMA wants:
 // P never leaves registers and needs no cross-lane shuffle.
-// Softmax statistics (running max / sum) are fp32.  The running max is kept on the RAW scores; exp is evaluated as
-// exp2(fma(s, scale*log2e, -max*scale*log2e)): one FMA + one v_exp per score.  Mask work (key padding, causal
-// diagonal) is only executed for tiles that contain a masked key; the O rescale only when some row's max moved.
+// Softmax statistics are fp32.  The exponent reference of a row is a LAZY running maximum of the raw scores: it only
+// moves when the row maximum outgrows it by more than 2^8 (softmax is invariant to the reference; P <= 256 meanwhile), so
+// the rescale of O runs about once per row block, not once per tile.  exp is exp2(fma(s, scale*log2e, -ref*scale*log2e)):
+// one packed FMA per two scores + one v_exp per score.  Mask work (key padding, causal diagonal) is only executed for
+// tiles that contain a masked key.
 // A query row whose keys are all masked yields 0 (the reference yields NaN there; it cannot happen with
 // right-padded inputs).
 #include <stdlib.h>

@@ -1,6 +1,9 @@
 // gemm_bf16_w8: 256x256x64 bf16 MFMA GEMM, EIGHT waves per workgroup (2 (M) x 4 (N), wave tile 128 x 64 = two waves per
 // SIMD), one persistent workgroup per CU.  The default kernel for chip-filling shapes.
-//   out[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+//   out[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on v_mfma_f32_16x16x32_bf16 (8 x 4 blocks per
+//   wave; chosen over 32x32x16 for its energy per FLOP: these GEMMs run at the socket power cap, see w16_body below).
+//   The K-loop description that follows is the 32x32x16 form's (w8_body, -DW8_MF32); w16_body keeps its structure with
+//   16-MFMA phases instead of 8-MFMA steps.
 //
 //   LDS (160 KiB = the whole CU)   A ring: 3 slots x 32 KiB (256 rows x 128 B), W ring: 2 slots x 32 KiB.
 //             The activation operand streams from HBM and is prefetched TWO K-tiles ahead; the weight operand is
@@ -373,10 +376,191 @@ __device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
   }
 }
 
+// ---- 16x16x32 form (the default; -DW8_MF32 builds the 32x32x16 form above instead) ------------------------------------------------------------------------------------------
+// Same tile, ring, DMA and barrier structure; the wave's 128 x 64 part is 8 x 4 blocks of v_mfma_f32_16x16x32_bf16.  On
+// random operand bits the 16x16x32 instruction draws less power per FLOP than 32x32x16 (tools/mfma_power.py: 2.06 vs
+// 1.84 PFLOP/s for register-resident loops at the throttle point), and that, not a pipe, is what limits these GEMMs.
+// A 64-deep K-tile = two 32-deep steps s0, s1, each split by X row blocks into two PHASES of 16 MFMAs:
+//   P0: X(s0, blocks 0..3) x W(s0)    reads X(s0, 4..7), W(s1, 0..1)
+//   P1: X(s0, 4..7) x W(s0)           reads X(s1, 0..3), W(s1, 2..3)        A(g+2) pieces 0..1
+//   P2: X(s1, 0..3) x W(s1)           reads X(s1, 4..7)                     A(g+2) pieces 2..3
+//   -- vmcnt(4) lgkmcnt(0) s_barrier: every read of A(g), W(g) is done; A(g+1), W(g+1) have landed --
+//   P3: X(s1, 4..7) x W(s1)           reads X'(s0, 0..3), W'(s0) of K-tile g+1   W(g+2) pieces 0..3 -> slot of W(g)
+// Fragment registers: two X sets and two W sets of four 16-row fragments (64 VGPRs) + 128 accumulators.
+#define W16_MFMAS(XC, WC, IB)                                                                               \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
+    acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[(IB) * 4 + q_][j_], 0, 0, 0);
+// interleave of one phase: 16 MFMAs, the first NRD of them followed by a fragment read, VMEM after the MFMAs in VM_MASK
+#define W16_SCHED(NRD, VM_MASK)                                                                             \
+  _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                       \
+    __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                                \
+    if (n_ < (NRD)) __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                                \
+    if (((VM_MASK) >> n_) & 1) __builtin_amdgcn_sched_group_barrier(W4_SGB_VMEM, 1, 0);                     \
+  }                                                                                                         \
+  __builtin_amdgcn_sched_barrier(0);
+
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void w16_body(const GemmArgs& p, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (int)((p.M + 255) / 256);
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  if (slot >= cnt) return;
+  const int nk = p.K / WBK;
+
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int x_off = wm * 128 * WROWB, w_off = wn * 64 * WROWB;
+
+  W4CurA<8> CA;
+  W4CurW CW;
+  CA.li = CW.li = slot;
+  CA.kt = CW.kt = 0;
+  w4_setup_a<8>(CA, p, base + slot, tiles_n, lda, wave, lane);
+  w4_setup_w(CW, p, base + slot, tiles_n, ldw, wave, lane);
+  auto advance_a = [&]() {
+    if (++CA.kt == nk) {
+      CA.kt = 0;
+      if (CA.li + slots < cnt) { CA.li += slots; w4_setup_a<8>(CA, p, base + CA.li, tiles_n, lda, wave, lane); }
+    }
+  };
+  auto advance_w = [&]() {
+    if (++CW.kt == nk) {
+      CW.kt = 0;
+      if (CW.li + slots < cnt) { CW.li += slots; w4_setup_w(CW, p, base + CW.li, tiles_n, ldw, wave, lane); }
+    }
+  };
+
+  int a_c = W_AOFF, a_1 = W_AOFF + W_SLOT, a_2 = W_AOFF + 2 * W_SLOT;
+  int w_c = W_WOFF, w_1 = W_WOFF + W_SLOT;
+
+  // prologue: A(0) W(0) | A(1) W(1)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_c, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_c, wave);
+  advance_w();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_1, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_1, wave);
+  advance_w();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // fragment of block `blk` (16 rows), 32-deep step s: row blk*16 + l16, 16-byte chunk s*4 + lq
+#define W16_F(OPER, BLK, S) w4_frag(OPER, (BLK) * 16 + l16, (S) * 4 + lq)
+#define W16_RD(DST, EXPR) if (W4_DO_READS) DST = EXPR;      // -DW4_NOREADS: the K-loop without its fragment reads (ablation)
+  bf16x8 xa[4], xb[4], wc[4], wn_[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xa[i] = W16_F(smem + a_c + x_off, i, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = W16_F(smem + w_c + w_off, j, 0);
+
+  constexpr int NST = (EPI == EPI_BF16) ? 16 : 32;      // global stores per wave and epilogue (full tile)
+  bool stores_pending = false;
+  int c_li = slot;
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* xs = smem + a_c + x_off;
+      const char* ws = smem + w_c + w_off;
+      // P0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W16_RD(xb[i], W16_F(xs, 4 + i, 0))
+      W16_RD(wn_[0], W16_F(ws, 0, 1))
+      W16_RD(wn_[1], W16_F(ws, 1, 1))
+      W16_MFMAS(xa, wc, 0)
+      W16_SCHED(6, 0)
+      // P1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W16_RD(xa[i], W16_F(xs, i, 1))
+      W16_RD(wn_[2], W16_F(ws, 2, 1))
+      W16_RD(wn_[3], W16_F(ws, 3, 1))
+      w4_piece_a<8>(CA, 0, smem + a_2, wave);
+      w4_piece_a<8>(CA, 1, smem + a_2, wave);
+      W16_MFMAS(xb, wc, 1)
+      W16_SCHED(6, (1 << 4) | (1 << 10))
+      // P2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W16_RD(xb[i], W16_F(xs, 4 + i, 1))
+      w4_piece_a<8>(CA, 2, smem + a_2, wave);
+      w4_piece_a<8>(CA, 3, smem + a_2, wave);
+      W16_MFMAS(xa, wn_, 0)
+      W16_SCHED(4, (1 << 4) | (1 << 10))
+      advance_a();
+      if (stores_pending) {
+        if (EPI == EPI_F32 && p.xb_out) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
+        stores_pending = false;
+      } else {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // P3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) W16_RD(xa[i], W16_F(smem + a_1 + x_off, i, 0))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) W16_RD(wc[j], W16_F(smem + w_1 + w_off, j, 0))
+#pragma unroll
+      for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_c, wave);
+      W16_MFMAS(xb, wn_, 1)
+      W16_SCHED(8, (1 << 2) | (1 << 6) | (1 << 10) | (1 << 14))
+      advance_w();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+    }
+    const int t = base + c_li;
+    int tm_, tn_;
+    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
+    const int64_t m_cur = (int64_t)tm_ * 256;
+    const int n_cur = tn_ * 256;
+#ifdef W4_NOEPI
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+    w16_epilogue<EPI, ACT, MODE>(acc, p, m_cur, n_cur, wm, wn, lane, smem + a_2 + wave * 4096);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+    // the next tile's first fragments are re-read here: they are not live across the epilogue, which needs the registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = W16_F(smem + a_c + x_off, i, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc[j] = W16_F(smem + w_c + w_off, j, 0);
+    stores_pending = (EPI == EPI_F32) && (MODE != 0 || !p.xb_out == !p.stats_part);
+#endif
+    c_li += slots;
+    if (c_li >= cnt) break;
+  }
+}
+
 template <int EPI, int ACT, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_w8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef W8_MF32      // the round-1 / early round-2 form on v_mfma_f32_32x32x16_bf16 (A/B builds, tools/w8_timing.py)
   w8_body<EPI, ACT, MODE>(p, smem);
+#else
+  w16_body<EPI, ACT, MODE>(p, smem);
+#endif
 }
 
 template <int EPI, int ACT, int MODE = 0>

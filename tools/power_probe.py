@@ -101,14 +101,35 @@ def attn(seconds):
                 seconds, flops=2 * 2 * S * S * H * B)
 
 
+def blaslt(seconds, only):
+    """Calibration only (never on the product path): the vendor library's bf16 GEMM (torch.matmul -> hipBLASLt) on the same
+    shapes and operand bits, no epilogue at all.  Does it get past the power cap where the w8 kernel does not?"""
+    dev = "cuda:0"
+    shapes = dict(SHAPES)
+    shapes["sq8k"] = (8192, 8192, 8192, "bf16", 0)
+    for name in only.split(","):
+        M, N, K, _, _ = shapes[name]
+        for data in ("randn", "zeros"):
+            A = torch.randn(M, K, device=dev).bfloat16()
+            W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+            if data == "zeros":
+                A.zero_(); W.zero_()
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            Wt = W.t()
+            measure(f"hipBLASLt {name} {M}x{N}x{K} {data}", lambda: torch.matmul(A, Wt, out=out), seconds, flops=2.0 * M * N * K, chunk=50)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--blaslt", action="store_true")
     ap.add_argument("--stages", action="store_true")
     ap.add_argument("--attn", action="store_true")
     ap.add_argument("--only", default="fc1")
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=3.0)
     a = ap.parse_args()
+    if a.blaslt:
+        return blaslt(a.seconds, a.only)
     if a.stages:
         return stages(a.seconds)
     if a.attn:

@@ -32,6 +32,12 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 #ifndef W8_ST_AUX
 #define W8_ST_AUX 2
 #endif
+// fp32 (residual) epilogue: sc1 = write-through.  Found while building the parked GEMM + LayerNorm launch
+// (tools/experimental/ln_tail): out-proj 253 -> 231 us isolated, fc2 541 -> 530; in the step -0.15 ms (A/B on one box,
+// 29.03 -> 28.88).  The bf16 epilogue keeps nt (sc1 there: +0.7 ms per step).
+#ifndef W8_ST_AUX_F32
+#define W8_ST_AUX_F32 16
+#endif
 #ifndef W8_LD_AUX
 #define W8_LD_AUX 2
 #endif
@@ -307,7 +313,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
         const int row = tt * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
         if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX_F32);
         if (produce_xb) {
           bf16x4 b;
 #pragma unroll

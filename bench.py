@@ -345,9 +345,11 @@ def main():
                         "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],
-                        "note": "peak = nominal 2.4 GHz dense figure.  On random operands this kernel is power-limited: the same "
-                                "instruction stream runs 1.42 PFLOP/s at 2.38 GHz on zero operands vs 1.03 at 1.80 GHz at the 1400 W cap (profiles/r2_v2/power_probe.txt), and moving its epilogue under the K-loop "
-                                "(tools/experimental/gemm_s8.hip: -15 % cycles per tile) returned as a lower clock, not as time (DESIGN.md 4.1)"}
+                        "note": "peak = nominal 2.4 GHz dense figure.  On random operands this kernel runs at the 1400 W socket power cap "
+                                "(shader clock ~1.9 of 2.4 GHz; the same instruction stream does 1.42 PFLOP/s on zero operands), as does the "
+                                "vendor library's GEMM on the same shape (hipBLASLt 1.17-1.19 PFLOP/s without bias / SiLU); the kernel uses "
+                                "v_mfma_f32_16x16x32_bf16 because it draws less power per FLOP than 32x32x16 (register-resident loops: 2.04 "
+                                "vs 1.82 PFLOP/s at the throttle point) - profiles/r2_v3/{power_probe,blaslt_calib,mfma_power}.txt, DESIGN.md 4"}
 
         if not args.no_extra_configs:
             extra = {}

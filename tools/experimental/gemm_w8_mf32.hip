@@ -1,7 +1,14 @@
+// PARKED (round 2): gemm_w8.hip as it was when BOTH forms lived in one file - the 32x32x16 K-loop (w8_body, its W8_TIMING
+// stamps and W8_A2 / W8_NOMFMA ablations; build with -DW8_MF32) next to the 16x16x32 K-loop that ships.  Measured A/B on one
+// box: step 28.59 ms (32x32x16) vs 27.55 ms (16x16x32); fc1 573 vs 545 us isolated.  To build a variant:
+//   cp tools/experimental/gemm_w8_mf32.hip cacophony_amd/csrc/gemm_w8.hip ; cp tools/experimental/gemm_w8_mf32_epilogue.h cacophony_amd/csrc/
+//   tools/build_variant.sh mf32 gemm_w8.hip -DW8_MF32 [-DW8_TIMING] ; git checkout cacophony_amd/csrc/gemm_w8.hip
 // gemm_bf16_w8: 256x256x64 bf16 MFMA GEMM, EIGHT waves per workgroup (2 (M) x 4 (N), wave tile 128 x 64 = two waves per
 // SIMD), one persistent workgroup per CU.  The default kernel for chip-filling shapes.
 //   out[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on v_mfma_f32_16x16x32_bf16 (8 x 4 blocks per
-//   wave; chosen over 32x32x16 for its energy per FLOP: these GEMMs run at the socket power cap).
+//   wave; chosen over 32x32x16 for its energy per FLOP: these GEMMs run at the socket power cap, see w16_body below).
+//   The K-loop description that follows is the 32x32x16 form's (w8_body, -DW8_MF32); w16_body keeps its structure with
+//   16-MFMA phases instead of 8-MFMA steps.
 //
 //   LDS (160 KiB = the whole CU)   A ring: 3 slots x 32 KiB (256 rows x 128 B), W ring: 2 slots x 32 KiB.
 //             The activation operand streams from HBM and is prefetched TWO K-tiles ahead; the weight operand is
@@ -12,10 +19,10 @@
 //             output-tile boundaries (the next tile's first K-tiles land while this tile's epilogue runs)
 //   LDS image lane-linear (DMA constraint); the bank swizzle (16-byte chunk c ^ ((row >> 1) & 7)) is applied to the
 //             per-lane SOURCE offset and undone on the ds_read_b128 side
-//   K-loop    rotated, four phases of 16 MFMAs per 64-deep K-tile: P0 P1 P2 | vmcnt(4) lgkmcnt(0) s_barrier | P3 (see
-//             w16_body).  Fragments are double-buffered in registers one phase ahead (also across K-tiles and output
-//             tiles): two X sets and two W sets of four 16-row fragments.  A wave that is stalled (DMA issue, fragment
-//             wait, barrier) leaves the SIMD's matrix pipe to its partner; nothing forces their phase.
+//   K-loop    rotated: body(g) = ks0 ks1 ks2 | vmcnt(4) lgkmcnt(0) s_barrier | ks3.  Fragments are double-buffered in
+//             registers one 16-deep step ahead (also across K-tiles and output tiles).  Per wave and 16-deep step: 8 MFMAs,
+//             6 fragment reads; per K-tile 4 A pieces (ks1, ks2) + 4 W pieces (ks3).  A wave that is stalled (DMA issue,
+//             fragment wait, barrier) leaves the SIMD's matrix pipe to its partner; nothing forces their phase.
 //   MFMA      operands swapped (weights = A operand) so that a lane owns 4 CONSECUTIVE n of one output row m
 //   epilogue  gemm_w8_epilogue.h: bias / SiLU / erf-GELU / residual / LayerNorm-fold forms in registers; 32-row slabs
 //             transposed through the wave's XOR-swizzled LDS slab so that every global access is a whole 128-byte row
@@ -23,18 +30,17 @@
 //   schedule  persistent; XCD x owns a contiguous run of tiles (n fastest), so the tiles that share an A row panel
 //             run together on one XCD's L2
 //
-// Anatomy (32x32x16 form, tools/w8_timing.py): per 256x256 tile at K = 768 the K-loop takes ~28 k cycles,
-// the epilogue 9.7 k (bf16) .. 11.6 k (SiLU) .. 44 k (fp32 + residual) with the matrix pipe idle; the epilogue is bound by
-// the CU's own issue / store path, not by HBM.  Ablation builds: -DW4_NOEPI, -DW4_NODMA, -DW4_NOREADS
-// (tools/build_variant.sh, tools/energy_ab.sh).  Retired siblings: the 32x32x16 form of this kernel with its timing stamps
-// (tools/experimental/gemm_w8_mf32.hip), 4-wave 128x128-per-wave form, phased p8, two-accumulator v8, two-workgroups-per-CU
-// d4, skewed-row-group s8 (git history / tools/experimental/).
+// Round-2 anatomy (tools/w8_timing.py): per 256x256 tile at K = 768 the K-loop takes ~28 k cycles (MFMA
+// pipe 88 % busy), the epilogue 9.7 k (bf16) .. 11.6 k (SiLU) .. 44 k (fp32 + residual) with the matrix pipe idle; the
+// epilogue is bound by the CU's own issue / store path, not by HBM.  Ablation builds: -DW4_NOEPI, -DW8_NOMFMA, -DW8_A2,
+// -DW8_TIMING (tools/build_variant.sh).  Retired siblings (4-wave 128x128-per-wave form, phased p8, two-accumulator v8,
+// two-workgroups-per-CU d4): git history / tools/experimental/.
 //
 // Reference ops replaced: nn.Linear + activation + residual add (audio_models/mae.py:55-61,69-74,92-97,133;
 // text_models/roberta.py:62-64,110,153,164; caco.py:35-37).
 #include "common.h"
 #include "kernels.h"
-#include "gemm_w8_epilogue.h"
+#include "gemm_w8_mf32_epilogue.h"
 
 namespace caco {
 namespace {
@@ -53,7 +59,11 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 #else
 #define W4_DO_READS 1
 #endif
+#ifdef W4_SAMEADDR
+#define W4_KOFF(kt) 0
+#else
 #define W4_KOFF(kt) ((kt) * (WBK * 2))
+#endif
 #define W4_SGB_MFMA 0x008
 #define W4_SGB_VMEM 0x010
 #define W4_SGB_DSRD 0x100
@@ -86,6 +96,9 @@ struct W4CurW {
 
 template <int NWV>
 __device__ __forceinline__ void w4_setup_a(W4CurA<NWV>& C, const GemmArgs& p, int t, int tiles_n, int lda, int wave, int lane) {
+#ifdef W4_SAMEADDR
+  t = 0;
+#endif
   int tm, tn;
   w4_decode(t, tiles_n, (int)((p.M + 255) / 256), p.ngroup, tm, tn);
   const int64_t m0 = (int64_t)tm * 256;
@@ -97,6 +110,9 @@ __device__ __forceinline__ void w4_setup_a(W4CurA<NWV>& C, const GemmArgs& p, in
   for (int it = 0; it < 32 / NWV; ++it) C.voff[it] = min(it * NWV * 8 + r8, last) * lda * 2 + chunk * 16;
 }
 __device__ __forceinline__ void w4_setup_w(W4CurW& C, const GemmArgs& p, int t, int tiles_n, int ldw, int wave, int lane) {
+#ifdef W4_SAMEADDR
+  t = 0;
+#endif
   int tm, tn;
   w4_decode(t, tiles_n, (int)((p.M + 255) / 256), p.ngroup, tm, tn);
   const int n0 = tn * 256;
@@ -125,10 +141,250 @@ __device__ __forceinline__ bf16x8 w4_frag(const char* oper, int row, int chunk) 
   return *reinterpret_cast<const bf16x8*>(oper + row * WROWB + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// ---- K-loop ------------------------------------------------------------------------------------------------------------
-// The wave's 128 x 64 part is 8 x 4 blocks of v_mfma_f32_16x16x32_bf16.  On random operand bits the 16x16x32 instruction
-// draws less power per FLOP than 32x32x16 (tools/mfma_power.py: 2.04 vs 1.82 PFLOP/s for register-resident loops at the
-// throttle point), and that, not a pipe, is what limits these GEMMs.
+#ifdef W8_NOMFMA      // ablation: the K-loop's memory side alone (DMA + fragment reads + barriers), no matrix instructions
+#define W8_MFMAS(XC, WC)                                                                         \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) asm volatile("" ::"v"(XC[q_]));               \
+  asm volatile("" ::"v"(WC[0]), "v"(WC[1]));
+#else
+#define W8_MFMAS(XC, WC)                                                                         \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[0], acc[0][0], 0, 0, 0);         \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[1], acc[1][0], 0, 0, 0);         \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[0], acc[0][1], 0, 0, 0);         \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[1], acc[1][1], 0, 0, 0);         \
+  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[2], acc[2][0], 0, 0, 0);         \
+  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[2], acc[2][1], 0, 0, 0);         \
+  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[0], XC[3], acc[3][0], 0, 0, 0);         \
+  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WC[1], XC[3], acc[3][1], 0, 0, 0);
+#endif
+#define W8_STEP(XN, WN, XA, WW, KS, XC, WC, DMA0, DMA1, DMA2, DMA3)                               \
+  if (W4_DO_READS) {                                                                             \
+    XN[0] = w4_frag(XA, 0 * 32 + frow, (KS) * 2 + fhalf);                                        \
+    WN[0] = w4_frag(WW, 0 * 32 + frow, (KS) * 2 + fhalf);                                        \
+  }                                                                                              \
+  DMA0;                                                                                          \
+  if (W4_DO_READS) XN[1] = w4_frag(XA, 1 * 32 + frow, (KS) * 2 + fhalf);                         \
+  DMA1;                                                                                          \
+  if (W4_DO_READS) {                                                                             \
+    WN[1] = w4_frag(WW, 1 * 32 + frow, (KS) * 2 + fhalf);                                        \
+    XN[2] = w4_frag(XA, 2 * 32 + frow, (KS) * 2 + fhalf);                                        \
+  }                                                                                              \
+  DMA2;                                                                                          \
+  if (W4_DO_READS) XN[3] = w4_frag(XA, 3 * 32 + frow, (KS) * 2 + fhalf);                         \
+  DMA3;                                                                                          \
+  W8_MFMAS(XC, WC)                                                                               \
+  _Pragma("unroll") for (int n_ = 0; n_ < 8; ++n_) {                                             \
+    __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                     \
+    if (n_ < 6) __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                         \
+    if (n_ == 1 || n_ == 2 || n_ == 4 || n_ == 5) __builtin_amdgcn_sched_group_barrier(W4_SGB_VMEM, 1, 0); \
+  }                                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+
+// (kernel bodies live in __device__ functions: the buffer-descriptor types they use are invisible to the host pass,
+// which otherwise drops the kernel's launch stub)
+// -DW8_TIMING (tools/w8_timing.py): wave 0 of every workgroup stamps s_memtime at the phase boundaries of each tile into
+// the 64-bit words that follow the output matrix (the tool allocates them): [wg][tile][0..4] = first in-loop barrier
+// passed, K-loop done, epilogue issued, post-epilogue barrier passed, (next tile's first barrier = stores retired)
+#ifdef W8_TIMING
+#define W8_STAMP(t, k)                                                                                      \
+  if (wave == 0 && lane == 0 && (t) < 32)                                                                   \
+    reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.out) +                                  \
+        (size_t)p.M * p.ldc * (EPI == EPI_BF16 ? 2 : 4))[((size_t)blockIdx.x * 32 + (t)) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define W8_STAMP(t, k)
+#endif
+
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void w8_body(const GemmArgs& p, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (int)((p.M + 255) / 256);
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  if (slot >= cnt) return;
+  const int nk = p.K / WBK;
+  // De-synchronise the CUs: identical tiles would otherwise march in lock step, and every workgroup's epilogue (stores,
+  // residual loads) would hit HBM in the same few microseconds while the memory system idles during the K-loops.
+  for (int z = (slot & 31) * p.stagger >> 5; z > 0; --z) __builtin_amdgcn_s_sleep(16);
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int x_off = wm * 128 * WROWB, w_off = wn * 64 * WROWB;
+
+  W4CurA<8> CA;
+  W4CurW CW;
+  CA.li = CW.li = slot;
+  CA.kt = CW.kt = 0;
+  w4_setup_a<8>(CA, p, base + slot, tiles_n, lda, wave, lane);
+  w4_setup_w(CW, p, base + slot, tiles_n, ldw, wave, lane);
+  auto advance_a = [&]() {
+    if (++CA.kt == nk) {
+      CA.kt = 0;
+      if (CA.li + slots < cnt) { CA.li += slots; w4_setup_a<8>(CA, p, base + CA.li, tiles_n, lda, wave, lane); }
+    }
+  };
+  auto advance_w = [&]() {
+    if (++CW.kt == nk) {
+      CW.kt = 0;
+      if (CW.li + slots < cnt) { CW.li += slots; w4_setup_w(CW, p, base + CW.li, tiles_n, ldw, wave, lane); }
+    }
+  };
+
+  int a_c = W_AOFF, a_1 = W_AOFF + W_SLOT, a_2 = W_AOFF + 2 * W_SLOT;
+  int w_c = W_WOFF, w_1 = W_WOFF + W_SLOT;
+
+  // prologue: A(0) W(0) | A(1) W(1)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_c, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_c, wave);
+  advance_w();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_a<8>(CA, it, smem + a_1, wave);
+  advance_a();
+#ifdef W8_A2
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
+#pragma unroll
+  for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_1, wave);
+  advance_w();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+  __builtin_amdgcn_s_barrier();
+  bf16x8 x0[4], w0[2], x1[4], w1[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x0[i] = w4_frag(smem + a_c + x_off, i * 32 + frow, fhalf);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) w0[j] = w4_frag(smem + w_c + w_off, j * 32 + frow, fhalf);
+
+  // Vector-memory operations retire in issue order.  Everything the FIRST barrier after an epilogue waits for
+  // (A(g+1), W(g+1)) was issued before that epilogue's stores, so that barrier may leave the stores in flight
+  // (vmcnt(4 + NST)); only the second one, a whole K-tile later, needs them retired.
+  constexpr int NST = (EPI == EPI_BF16) ? 16 : 32;      // global stores per wave and epilogue (full tile)
+  bool stores_pending = false;
+  int c_li = slot;
+#ifdef W8_TIMING
+  int tile_no = 0;
+#endif
+  while (true) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* xa = smem + a_c + x_off;
+      const char* ww = smem + w_c + w_off;
+#ifdef W8_A2
+      // experiment: A one K-tile ahead only (what a two-slot A ring allows): W(g+1) in ks0, A(g+2) in the previous ks3
+      W8_STEP(x1, w1, xa, ww, 1, x0, w0, w4_piece_w<8>(CW, 0, ldw, smem + w_1, wave), w4_piece_w<8>(CW, 1, ldw, smem + w_1, wave),
+              w4_piece_w<8>(CW, 2, ldw, smem + w_1, wave), w4_piece_w<8>(CW, 3, ldw, smem + w_1, wave))
+      advance_w();
+      W8_STEP(x0, w0, xa, ww, 2, x1, w1, (void)0, (void)0, (void)0, (void)0)
+      W8_STEP(x1, w1, xa, ww, 3, x0, w0, (void)0, (void)0, (void)0, (void)0)
+#else
+      // ks0: compute (g,0), read (g,1)
+      W8_STEP(x1, w1, xa, ww, 1, x0, w0, (void)0, (void)0, (void)0, (void)0)
+      // ks1: compute (g,1), read (g,2); A(g+2) pieces 0..1
+      W8_STEP(x0, w0, xa, ww, 2, x1, w1, w4_piece_a<8>(CA, 0, smem + a_2, wave), (void)0, w4_piece_a<8>(CA, 1, smem + a_2, wave), (void)0)
+      // ks2: compute (g,2), read (g,3); A(g+2) pieces 2..3
+      W8_STEP(x1, w1, xa, ww, 3, x0, w0, w4_piece_a<8>(CA, 2, smem + a_2, wave), (void)0, w4_piece_a<8>(CA, 3, smem + a_2, wave), (void)0)
+      advance_a();
+#endif
+      // A(g+1) and W(g+1) have landed (only A(g+2), and right after an epilogue its stores, may still be in flight);
+      // every wave is done reading A(g), W(g)
+#ifdef W8_A2
+      stores_pending = false;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+      if (stores_pending) {
+        // the producer form (bf16 copy + row statistics) issues 80 stores: the counter saturates at 63, which still
+        // retires everything older than the stores
+        if (EPI == EPI_F32 && p.xb_out) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
+        stores_pending = false;
+      } else {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef W8_TIMING
+      if (kt == 0) { W8_STAMP(tile_no, 0) }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // ks3: compute (g,3), read (g+1,0) (possibly of the next output tile); W(g+2) -> slot of W(g)
+#ifdef W8_A2
+      // A(g+2) -> the slot of A(g) (all of its fragments have been read): with two A slots this is the earliest point
+      W8_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_a<8>(CA, 0, smem + a_2, wave),
+              w4_piece_a<8>(CA, 1, smem + a_2, wave), w4_piece_a<8>(CA, 2, smem + a_2, wave), w4_piece_a<8>(CA, 3, smem + a_2, wave))
+      advance_a();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+#else
+      W8_STEP(x0, w0, smem + a_1 + x_off, smem + w_1 + w_off, 0, x1, w1, w4_piece_w<8>(CW, 0, ldw, smem + w_c, wave),
+              w4_piece_w<8>(CW, 1, ldw, smem + w_c, wave), w4_piece_w<8>(CW, 2, ldw, smem + w_c, wave),
+              w4_piece_w<8>(CW, 3, ldw, smem + w_c, wave))
+      advance_w();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+#endif
+    }
+    const int t = base + c_li;
+    int tm_, tn_;
+    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
+    const int64_t m_cur = (int64_t)tm_ * 256;
+    const int n_cur = tn_ * 256;
+#ifdef W4_NOEPI
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+    W8_STAMP(tile_no, 1)
+    w8_epilogue<EPI, ACT, MODE>(acc, p, m_cur, n_cur, wm, wn, lane, smem + a_2 + wave * 4096);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W8_STAMP(tile_no, 2)
+    __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+    W8_STAMP(tile_no, 3)
+#ifdef W8_TIMING
+    ++tile_no;
+#endif
+    // the next tile's first fragments are re-read here (ks3 already fetched them once): this way they are not live
+    // across the epilogue, which needs the registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = w4_frag(smem + a_c + x_off, i * 32 + frow, fhalf);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w0[j] = w4_frag(smem + w_c + w_off, j * 32 + frow, fhalf);
+#ifndef W4_STRICT_WAIT
+    // a full tile issued exactly NST stores per wave.  Only the fp32 + residual epilogue uses the relaxed wait:
+    // measured -4..-5 % on the out-proj / fc2 shapes, but +29 % on the bf16 QKV shape (N = 2304), where letting
+    // every CU run ahead with 16 more stores in flight makes the HBM write bursts collide
+    // (buffer stores of rows past M are dropped by the descriptor but still issue, so the count is exact)
+#ifdef W8_RELAX_BF16
+    stores_pending = (MODE != 0 || !p.xb_out == !p.stats_part);
+#else
+    stores_pending = (EPI == EPI_F32) && (MODE != 0 || !p.xb_out == !p.stats_part);
+#endif
+#endif
+#endif
+    c_li += slots;
+    if (c_li >= cnt) break;
+  }
+}
+
+// ---- 16x16x32 form (the default; -DW8_MF32 builds the 32x32x16 form above instead) ------------------------------------------------------------------------------------------
+// Same tile, ring, DMA and barrier structure; the wave's 128 x 64 part is 8 x 4 blocks of v_mfma_f32_16x16x32_bf16.  On
+// random operand bits the 16x16x32 instruction draws less power per FLOP than 32x32x16 (tools/mfma_power.py: 2.06 vs
+// 1.84 PFLOP/s for register-resident loops at the throttle point), and that, not a pipe, is what limits these GEMMs.
 // A 64-deep K-tile = two 32-deep steps s0, s1, each split by X row blocks into two PHASES of 16 MFMAs:
 //   P0: X(s0, blocks 0..3) x W(s0)    reads X(s0, 4..7), W(s1, 0..1)
 //   P1: X(s0, 4..7) x W(s0)           reads X(s1, 0..3), W(s1, 2..3)        A(g+2) pieces 0..1
@@ -305,7 +561,11 @@ __device__ __forceinline__ void w16_body(const GemmArgs& p, char* smem) {
 template <int EPI, int ACT, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_w8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef W8_MF32      // the round-1 / early round-2 form on v_mfma_f32_32x32x16_bf16 (A/B builds, tools/w8_timing.py)
+  w8_body<EPI, ACT, MODE>(p, smem);
+#else
   w16_body<EPI, ACT, MODE>(p, smem);
+#endif
 }
 
 template <int EPI, int ACT, int MODE = 0>

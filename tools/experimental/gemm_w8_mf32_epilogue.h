@@ -1,6 +1,7 @@
-// Epilogue of the 128 x 64 per-wave output tile of gemm_bf16_w8 (8 x 4 blocks of v_mfma_f32_16x16x32_bf16, operands swapped
-// so that a lane owns 4 consecutive n of one output row m).  (The 32x32x16 form's epilogue, also used by the parked d4 / s8
-// kernels: tools/experimental/gemm_w8_mf32_epilogue.h.)
+// PARKED with gemm_w8_mf32.hip: both accumulator layouts' epilogues (w8_epilogue for 32x32x16, w16_epilogue for 16x16x32).
+// Epilogue of the 128 x 64 per-wave output tile (4 x 2 blocks of v_mfma_f32_32x32x16_bf16, operands swapped so that a lane
+// owns 4 consecutive n of one output row m), shared by the one-workgroup-per-CU 256x256 kernel (gemm_w4.hip, w8) and the
+// two-workgroups-per-CU 256x128 kernel (gemm_d4.hip).
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -41,15 +42,167 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 #ifndef W8_LD_AUX
 #define W8_LD_AUX 2
 #endif
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void w8_epilogue(const f32x16 (&acc)[4][2], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
+  const int lm = lane & 31, lh = lane >> 5;
+  const int rrow = lane >> 3, c8 = lane & 7;            // read-back: 8 rows x 128 B per instruction
+  const int64_t mw = m0 + wm * 128;
+  const int nw = n0 + wn * 64;
+  const int rows = (int)min((int64_t)128, p.M - mw);    // valid rows of this wave's part (may be <= 0)
+  const bool has_bias = MODE ? true : p.bias != nullptr;
+  if constexpr (EPI == EPI_BF16) {
+    // per 32-row block row: 32 x 64 bf16 slab, 128-byte pitch, 16-byte chunk c of row r at c ^ (r & 7).
+    // Bias (and the LayerNorm-fold column sums) are re-read from L1 per 4-column group instead of being held in 32-64
+    // registers across the whole epilogue: the accumulators already fill half the register file.
+    const int rowb = p.ldc * 2;
+    const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    const bool fold = MODE ? MODE == 3 : p.fold_mr != nullptr;      // LayerNorm folded into this GEMM (kernels.h)
+    const float* bias_l = has_bias ? p.bias + nw + lh * 4 : nullptr;
+    const float* c1_l = fold ? p.fold_c1 + nw + lh * 4 : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float nmr = 0.f, rstd = 1.f;                   // out = rstd * acc + (-mean * rstd) * c1 + bias
+      if (fold) {
+        const int64_t m = min(mw + i * 32 + lm, p.M - 1);
+        const float2 mr = *reinterpret_cast<const float2*>(p.fold_mr + 2 * m);
+        rstd = mr.y;
+        nmr = -mr.x * mr.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 bb = has_bias ? *reinterpret_cast<const f32x4*>(bias_l + j * 32 + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (fold) {
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(c1_l + j * 32 + g * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] = __builtin_fmaf(nmr, cc[r], bb[r]);
+          }
+          bf16x4 o;
+#ifdef W8_SILU_SCALAR
+          if constexpr (false) {
+#else
+          if constexpr (ACT == ACT_SILU) {
+#endif
+            // x * sigmoid(x) on register PAIRS: one wave issues an instruction every ~12 cycles whatever it is, so the
+            // scale, the 1 + e and the final product go through the packed ops (3 packed + 4 transcendental per pair
+            // instead of 9 scalar): v_pk_mul, 2 x v_exp, v_pk_add, 2 x v_rcp, v_pk_mul
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              f32x2 x;
+              x[0] = MODE == 1 ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
+              x[1] = MODE == 1 ? acc[i][j][g * 4 + r + 1] + bb[r + 1] : __builtin_fmaf(acc[i][j][g * 4 + r + 1], rstd, bb[r + 1]);
+              const f32x2 t = x * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+              const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.f, 1.f};
+              const f32x2 y = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+              o[r] = (bf16_t)y[0];
+              o[r + 1] = (bf16_t)y[1];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = MODE == 1 ? acc[i][j][g * 4 + r] + bb[r] : __builtin_fmaf(acc[i][j][g * 4 + r], rstd, bb[r]);
+              o[r] = (bf16_t)w4_epi_act<ACT>(x);
+            }
+          }
+          *reinterpret_cast<bf16x4*>(slab + lm * 128 + (((j * 4 + g) ^ (lm & 7)) << 4) + lh * 8) = o;
+        }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+#ifdef W4_NOSTORE
+        if (v[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, 0);
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, W8_ST_AUX);
+#endif
+      }
+    }
+  } else {   // EPI_F32: eight 32 x 32 fp32 slabs (128-byte pitch); the residual of slab s+1 is fetched while slab s is processed
+    const int rowb = p.ldc * 4;
+    const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
+    const bool has_resid = MODE ? (MODE == 2 || MODE == 4) : p.resid != nullptr;
+    const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
+    const bool produce_st = MODE ? MODE == 4 : p.stats_part != nullptr;
+    const __amdgpu_buffer_rsrc_t out_r =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
+    const int voff = rrow * rowb + c8 * 16;
+    const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
+        produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
 #ifndef W8_RES_AHEAD
 #define W8_RES_AHEAD 1      // residual slabs in flight ahead of the one being processed (2 and 3 measured: no gain)
 #endif
-// 16x16x32 accumulator layout: acc[ib][jb] is a 16 (m) x 16 (n) block, lane l holds m = ib*16 + (l & 15) and the four
-// consecutive n = jb*16 + 4*(l >> 4) + r.  Slabs are 32 rows x 128 bytes; a write instruction covers 16 rows per 16-lane
-// group, so the chunk swizzle is (row >> 1) & 7 (the operand tiles' one).
-// bf16: per 32-row block row a 32 x 64 bf16 slab.  Bias (and the LayerNorm-fold column sums) are re-read from L1 per
-// 4-column group instead of being held in 32-64 registers across the whole epilogue: the accumulators already fill half
-// the register file.  fp32: eight 32 x 32 fp32 slabs, the residual of slab s+1 fetched while slab s is processed.
+    constexpr int RA = W8_RES_AHEAD, RN = RA + 1;
+    u32x4 res[RN][4];
+    float st1[4][4], st2[4][4];
+    auto fetch = [&](int s, u32x4 (&dst)[4]) {
+      const int i = s >> 1, j = s & 1;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
+    };
+    if (has_resid) {
+#pragma unroll
+      for (int s0 = 0; s0 < RA; ++s0) fetch(s0, res[s0 % RN]);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int i = s >> 1, j = s & 1;
+      if (has_resid && s + RA < 8) fetch(s + RA, res[(s + RA) % RN]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][g * 4 + r];
+        if (has_bias) v += *reinterpret_cast<const f32x4*>(p.bias + nw + j * 32 + g * 8 + lh * 4);
+        *reinterpret_cast<f32x4*>(slab + lm * 128 + (((g * 2 + lh) ^ (lm & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = tt * 8 + rrow;
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ (row & 7)) << 4));
+        if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX);
+        if (produce_xb) {         // bf16 copy of the new rows: the next (LayerNorm-folded) GEMM's A operand, default cache policy
+          bf16x4 b;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff >> 1), ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
+        }
+        if (produce_st) {       // row statistics of the NEW residual rows, for the next LayerNorm-folded GEMM
+          const float a1 = (v[0] + v[1]) + (v[2] + v[3]);
+          const float a2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
+        }
+      }
+    }
+    if (produce_st) {           // 8 lanes (c8) share a row: reduce, lane c8 == 0 writes this wave's 64-column partial
+      const int nslot = p.N >> 6, slot = nw >> 6;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float a1 = st1[i][tt], a2 = st2[i][tt];
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+          }
+          const int64_t m = mw + i * 32 + tt * 8 + rrow;
+          if (c8 == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_part + (m * nslot + slot) * 2) = make_float2(a1, a2);
+        }
+    }
+  }
+}
+
+// The same epilogue for the 16x16x32 accumulator layout (W8_MF16): acc[ib][jb] is a 16 (m) x 16 (n) block, lane l holds
+// m = ib*16 + (l & 15) and the four consecutive n = jb*16 + 4*(l >> 4) + r.  Slabs are 32 rows x 128 bytes as above, but a
+// write instruction now covers 16 rows per 16-lane group, so the chunk swizzle is (row >> 1) & 7 (the operand tiles' one).
 template <int EPI, int ACT, int MODE>
 __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
   const int l16 = lane & 15, lq = lane >> 4;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of the persistent w8 GEMM, from s_memtime stamps (build: tools/build_variant.sh w8time gemm_w4.hip -DW8_TIMING;
+"""Phase timeline of the persistent w8 GEMM, from s_memtime stamps (build from the parked 32x32x16 form, see the header of tools/experimental/gemm_w8_mf32.hip: build_variant.sh w8time gemm_w8.hip -DW8_MF32 -DW8_TIMING;
 run with CACO_LIB_PATH=cacophony_amd/_variants/libcaco_hip_w8time.so).  Prints, per shape, the mean cycles per tile of
   K-loop (first barrier -> K-loop done) | epilogue issue | wait at the post-epilogue barrier | next tile's first K-tile incl. store drain
 and the spread of the workgroups' epilogue start times."""

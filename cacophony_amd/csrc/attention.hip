@@ -41,6 +41,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef ATTN_ST_AUX
+#define ATTN_ST_AUX 0      // cache policy of the output stores (2 = nt, 16 = sc1): A/B switch, tools/build_variant.sh
+#endif
+
 namespace caco {
 namespace {
 
@@ -329,7 +333,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       const int L = it * 64 + lane;
       const int r = L / KCH, c = L % KCH;
       const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * OPITCH + c * 16);
-      __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, ATTN_ST_AUX);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging block is reused by the next query block
   }

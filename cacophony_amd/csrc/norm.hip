@@ -46,7 +46,11 @@ __device__ __forceinline__ void ln_row(f32x4 (&v)[MAXC], int nchunk, int lane, i
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)y[r];
+#ifdef LN_ST_NT       // A/B switch (tools/build_variant.sh): streaming stores of the bf16 rows
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(ob + ch * 4));
+#else
         *reinterpret_cast<bf16x4*>(ob + ch * 4) = o;
+#endif
       }
     }
   }

@@ -106,18 +106,25 @@ __device__ __forceinline__ void w4_setup_w(W4CurW& C, const GemmArgs& p, int t, 
   C.voff = r8 * ldw * 2 + chunk * 16;
 }
 
+// cache policy of the operand DMA loads (0 default, 2 = nt, 16 = sc1): A/B switches, tools/build_variant.sh
+#ifndef W8_A_AUX
+#define W8_A_AUX 0
+#endif
+#ifndef W8_W_AUX
+#define W8_W_AUX 0
+#endif
 // piece `it` of this wave's share of an operand K-tile: 8 rows x 128 B = one wave instruction
 template <int NWV>
 __device__ __forceinline__ void w4_piece_a(const W4CurA<NWV>& C, int it, char* slot, int wave) {
 #ifndef W4_NODMA
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * NWV + wave) * 1024), 16, C.voff[it], W4_KOFF(C.kt), 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * NWV + wave) * 1024), 16, C.voff[it], W4_KOFF(C.kt), 0, W8_A_AUX);
 #endif
 }
 template <int NWV>
 __device__ __forceinline__ void w4_piece_w(const W4CurW& C, int it, int ldw, char* slot, int wave) {
 #ifndef W4_NODMA
   __builtin_amdgcn_raw_ptr_buffer_load_lds(C.r, (lds_vptr)(slot + (it * NWV + wave) * 1024), 16, C.voff,
-                                           W4_KOFF(C.kt) + it * NWV * 8 * ldw * 2, 0, 0);
+                                           W4_KOFF(C.kt) + it * NWV * 8 * ldw * 2, 0, W8_W_AUX);
 #endif
 }
 

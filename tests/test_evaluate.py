@@ -1,0 +1,242 @@
+"""cacophony_amd.evaluate: the reference's evaluation drivers (src/eval/eval_caco_torch.py:231-408) in batched form.
+
+CPU: the host bookkeeping against known answers, the wrappers' keyword contract, and the whole driver flow with the
+device pieces (front end, towers, scoring) replaced by NumPy stand-ins that enforce the real functions' preconditions.
+GPU: the same drivers on the real pieces against the reference's own procedure - one clip, one caption at a time,
+host matmul and argsort."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from cacophony_amd import config as C
+from cacophony_amd import evaluate as E
+from cacophony_amd import frontend, retrieval, synth
+
+TEXT_VOCAB = 1024
+
+
+class StubTokenizer:
+    """RobertaTokenizerFast as eval_caco_torch.py:216-221 calls it; ids in the tiny model's vocabulary."""
+
+    def __call__(self, texts, padding=None, truncation=None, max_length=None, return_tensors=None):
+        assert padding == "max_length" and truncation is True and return_tensors == "pt" and len(texts) == 1
+        ids = torch.ones(len(texts), max_length, dtype=torch.int64)          # <pad> = 1
+        mask = torch.zeros_like(ids)
+        for i, t in enumerate(texts):
+            toks = [0] + [4 + sum(ord(c) * (j + 1) for j, c in enumerate(w)) % (TEXT_VOCAB - 4) for w in t.split()][: max_length - 2] + [2]
+            ids[i, : len(toks)] = torch.tensor(toks)
+            mask[i, : len(toks)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
+class ToyProcessor:
+    """The slice of the reference's dataset processors the drivers touch."""
+
+    class config:
+        sampling_rate = 16000
+
+    def __init__(self, clips, descriptions):
+        self.clips, self.descriptions = clips, descriptions
+
+    def get_filepaths_and_descriptions(self, current_split=""):
+        return [f"/data/{current_split}/{name}.wav" for name in self.clips], self.descriptions, None
+
+    def load(self, path, sr):
+        assert sr == 16000
+        return self.clips[E.audio_name_of(path)]
+
+
+def _toy_dataset(n_clips=7, seed=5):
+    rng = np.random.default_rng(seed)
+    classes = ["dog bark", "rain", "siren"]
+    clips, desc = {}, {}
+    for i in range(n_clips):
+        n = int(rng.integers(40000, 160000))
+        clips[f"clip{i:02d}"] = synth.make_waveform(100 + i)[:n].astype(np.float32)
+        label = classes[i % len(classes)]
+        caps = [label] + [f"{label} take {i} version {j}" for j in range(1 + i % 3)]
+        desc[f"clip{i:02d}"] = {"description": caps}
+    return ToyProcessor(clips, desc), classes
+
+
+# ----------------------------------------------------------------------------------------------------------- CPU
+def test_host_bookkeeping_known_answers():
+    assert E.audio_name_of("/a/b/c/1-100032-A-0.wav") == "1-100032-A-0"
+    assert list(E._chunks(5, 2)) == [(0, 2), (2, 4), (4, 5)] and list(E._chunks(0, 4)) == []
+    desc = {"x": {"description": ["rain", "heavy rain"]}, "y": {"description": ["dog"]}, "z": {"description": ["rain"]}}
+    labels, idx = E.class_index_map(desc)
+    assert labels == ["dog", "rain"] and idx == {"dog": 0, "rain": 1}
+    all_audio, all_text, gt_at, gt_ta = E.retrieval_ground_truth(["/s/x.wav", "/s/y.wav", "/s/z.wav"], desc)
+    assert all_audio == ["x", "y", "z"] and all_text == ["rain", "heavy rain", "dog", "rain"]
+    assert gt_at == {"x": ["rain", "heavy rain"], "y": ["dog"], "z": ["rain"]}
+    assert gt_ta == {"rain": "z", "heavy rain": "x", "dog": "y"}          # a shared caption keeps the last clip (:381)
+
+
+def test_wrappers_pass_the_reference_keywords():
+    seen = {}
+
+    class Rec:
+        def get_audio_embedding(self, **kw):
+            seen["a"] = kw
+            return torch.zeros(1, 4)
+
+        def get_text_embedding(self, **kw):
+            seen["t"] = kw
+            return torch.zeros(1, 4)
+
+    ab = {k: torch.zeros(1) for k in ("audio_patches", "audio_time_inds", "audio_freq_inds", "audio_mask")}
+    E.compute_audio_embedding(Rec(), ab)
+    E.compute_text_embedding(Rec(), {"text_input_ids": torch.zeros(1), "text_mask": torch.zeros(1)})
+    assert {k: v for k, v in seen["a"].items() if k not in ab} == dict(deterministic=True, return_hidden_state=False, normalize=True)
+    assert set(seen["a"]) - {"deterministic", "return_hidden_state", "normalize"} == set(ab)
+    assert {k: v for k, v in seen["t"].items() if not k.startswith("text_")} == dict(deterministic=True, return_hidden_state=False, normalize=True)
+
+
+def test_load_audio_without_decoder_says_so():
+    with pytest.raises(ImportError, match="soundfile"):
+        E.load_audio("/nonexistent.wav", 16000)
+
+
+def _install_cpu_stand_ins(monkeypatch):
+    """The device pieces replaced by host code with the same contracts (shapes, dtypes, argument meaning)."""
+    dim = 16
+
+    def prepare_text_batch(text, tokenizer, max_text_len, device=None):
+        tok = tokenizer([text], padding="max_length", truncation=True, max_length=max_text_len, return_tensors="pt")
+        return {"text_input_ids": tok["input_ids"], "text_mask": tok["attention_mask"]}
+
+    def prepare_audio_batch(audio, datasetconfig, device=None, lengths=None):
+        assert isinstance(audio, list) and all(np.ndim(c) == 1 and c.dtype == np.float32 for c in audio)
+        feats = torch.tensor([[float(np.mean(c ** 2)), float(len(c))] for c in audio])
+        return {"audio_patches": feats, "audio_time_inds": feats, "audio_freq_inds": feats, "audio_mask": feats}
+
+    class Model:
+        logit_scale = torch.tensor(math.log(10.0))
+
+        def get_audio_embedding(self, audio_patches, audio_time_inds, audio_freq_inds, audio_mask, deterministic, return_hidden_state, normalize):
+            assert deterministic and not return_hidden_state and normalize
+            g = torch.Generator().manual_seed(0)
+            proj = torch.randn(2, dim, generator=g)
+            return torch.nn.functional.normalize(torch.tanh(audio_patches / torch.tensor([0.1, 1e5])) @ proj, dim=1)
+
+        def get_text_embedding(self, text_input_ids, text_mask, deterministic, return_hidden_state, normalize):
+            assert deterministic and not return_hidden_state and normalize and text_input_ids.dtype == torch.int64
+            g = torch.Generator().manual_seed(1)
+            table = torch.randn(TEXT_VOCAB, dim, generator=g)
+            return torch.nn.functional.normalize((table[text_input_ids] * text_mask[..., None]).sum(1), dim=1)
+
+    def zs_scores(audio_emb, class_text_emb, target_idx, logit_scale=0.0, ks=(1,)):
+        logits = math.exp(logit_scale) * audio_emb @ class_text_emb.T
+        order = torch.argsort(-logits, dim=-1, stable=True).numpy()
+        tgt = np.asarray(target_idx).reshape(-1)
+        assert tgt.shape[0] == order.shape[0]
+        return {str(int(k)): float((order[:, :int(k)] == tgt[:, None]).any(1).mean()) for k in ks}
+
+    def retrieval_scores(audio_emb, text_emb, k=10, sim=None):
+        logits = text_emb @ audio_emb.T
+        at = torch.argsort(-logits.T, dim=-1, stable=True)[:, :k].to(torch.int32)
+        ta = torch.argsort(-logits, dim=-1, stable=True)[:, :k].to(torch.int32)
+        return logits, at, ta
+
+    monkeypatch.setattr(frontend, "prepare_text_batch", prepare_text_batch)
+    monkeypatch.setattr(frontend, "prepare_audio_batch", prepare_audio_batch)
+    monkeypatch.setattr(retrieval, "zs_classification_scores", zs_scores)
+    monkeypatch.setattr(retrieval, "audio_retrieval_scores", retrieval_scores)
+    return Model()
+
+
+def _reference_procedure(model, tok, proc, cfg, classes_prefix, device=None):
+    """The reference's loops as written (eval_caco_torch.py:289-408): one clip / one caption at a time, host matmul and
+    full argsort.  Returns (top-1 accuracy, at metric dict, ta metric dict)."""
+    filepaths, descriptions, _ = proc.get_filepaths_and_descriptions(current_split="test")
+    labels, cmap = E.class_index_map(descriptions)
+    class_emb = torch.cat([E.compute_text_embedding(model, frontend.prepare_text_batch(classes_prefix + c, tok, cfg.max_text_len, device))
+                           for c in labels], 0).float().cpu()
+    hits, a_embs, t_embs = 0, [], []
+    all_audio, all_text, gt_at, gt_ta = E.retrieval_ground_truth(filepaths, descriptions)
+    for fp in filepaths:
+        name = E.audio_name_of(fp)
+        emb = E.compute_audio_embedding(model, frontend.prepare_audio_batch([proc.load(fp, 16000)], cfg, device)).float().cpu()
+        logits = float(torch.exp(model.logit_scale)) * emb @ class_emb.T
+        hits += int(int(torch.argsort(-logits, dim=-1, stable=True)[0, 0]) == cmap[descriptions[name]["description"][0]])
+        a_embs.append(emb)
+        for cap in descriptions[name]["description"]:
+            t_embs.append(E.compute_text_embedding(model, frontend.prepare_text_batch(cap, tok, cfg.max_text_len, device)).float().cpu())
+    A, T = torch.cat(a_embs, 0), torch.cat(t_embs, 0)
+    logits_ar = T @ A.T
+    at = retrieval.compute_retrieval_metric(torch.argsort(-logits_ar.T, dim=-1, stable=True).numpy(), all_audio, all_text, gt_at)
+    ta = retrieval.compute_retrieval_metric(torch.argsort(-logits_ar, dim=-1, stable=True).numpy(), all_text, all_audio, gt_ta, "ta")
+    return hits / len(filepaths), at, ta
+
+
+def test_drivers_flow_on_cpu_stand_ins(monkeypatch):
+    """zs_classification / audio_retrieval end to end (batches of 3 over 7 clips: a ragged last batch) equal the
+    reference's one-at-a-time procedure on the same stand-in model."""
+    model = _install_cpu_stand_ins(monkeypatch)
+    proc, _ = _toy_dataset()
+    cfg = C.DatasetConfig(patches_seq_len=500, max_text_len=16)
+    tok = StubTokenizer()
+    acc = E.zs_classification(model, tok, proc, cfg, subdir_name="test", load_audio_fn=proc.load, batch_size=3, verbose=False)
+    out = E.audio_retrieval(model, tok, proc, cfg, eval_split="test", load_audio_fn=proc.load, batch_size=3, verbose=False)
+    ref_acc, ref_at, ref_ta = _reference_procedure(model, tok, proc, cfg, "This is a sound of ")
+    assert acc == pytest.approx(ref_acc)
+    for name in ("R1", "R5", "R10", "mAP10"):
+        assert out["audio_to_text"][name] == ref_at[name] and out["text_to_audio"][name] == ref_ta[name]
+    emb = E.compute_all_class_embeddings(model, tok, ["rain", "siren"], 16, prefix="This is a sound of ", batch_size=1)
+    one = E.compute_text_embedding(model, frontend.prepare_text_batch("This is a sound of siren", tok, 16))
+    assert emb.shape == (2, 16) and torch.allclose(emb[1:], one)
+
+
+# ----------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_drivers_on_the_device(tiny_state):
+    """The batched drivers on the real front end, towers and device scoring.  A random-weight model maps every clip to
+    nearly the same embedding (cosines up to 0.99997, rank gaps down to 1e-6 in the oracle), so the checks are made
+    robust to near-ties: (1) a clip embedded in a ragged batch equals the clip embedded alone (the reference's way);
+    (2) the zero-shot accuracy equals a float64 host scoring of the same embeddings (top-1 margins are checked to be
+    far above fp32 noise); (3) the retrieval metrics are those of the device ranking of the same embeddings, lined up
+    with the right names, and that ranking agrees with a float64 host ranking value for value at every rank."""
+    from cacophony_amd.model import CACO
+    a, t, cc = C.tiny_configs(2)
+    assert t.vocab_size == TEXT_VOCAB
+    model = CACO(a, t, cc, device="cuda:0").load_state_dict(tiny_state)
+    proc, _ = _toy_dataset()
+    cfg = C.DatasetConfig(patches_seq_len=500, max_text_len=16)
+    tok = StubTokenizer()
+    filepaths, descriptions, _ = proc.get_filepaths_and_descriptions(current_split="test")
+    clips = [proc.load(fp, 16000) for fp in filepaths]
+    all_audio, all_text, gt_at, gt_ta = E.retrieval_ground_truth(filepaths, descriptions)
+    labels, cmap = E.class_index_map(descriptions)
+
+    A = torch.cat([E.embed_clips(model, clips[lo:hi], cfg) for lo, hi in E._chunks(len(clips), 3)], 0)
+    T = E.embed_texts(model, tok, all_text, cfg.max_text_len)
+    Cemb = E.compute_all_class_embeddings(model, tok, labels, cfg.max_text_len, prefix="This is a sound of ")
+    assert A.shape == (len(clips), 768) and T.shape == (len(all_text), 768) and Cemb.shape == (len(labels), 768) and A.is_cuda
+    for i in (0, 3, 6):                                                 # (1) batch of three ragged clips vs batch of one
+        alone = E.compute_audio_embedding(model, frontend.prepare_audio_batch([clips[i]], cfg))
+        assert torch.nn.functional.cosine_similarity(alone, A[i:i + 1]).item() > 0.9999
+
+    A64, T64, C64 = (x.double().cpu().numpy() for x in (A, T, Cemb))
+    logits = math.exp(float(model.logit_scale)) * A64 @ C64.T           # (2)
+    top2 = -np.sort(-logits, axis=1)[:, :2]
+    assert (top2[:, 0] - top2[:, 1]).min() > 1e-4
+    target = np.array([cmap[descriptions[n]["description"][0]] for n in all_audio])
+    acc = E.zs_classification(model, tok, proc, cfg, subdir_name="test", load_audio_fn=proc.load, batch_size=3, verbose=False)
+    assert acc == pytest.approx(float((logits.argmax(1) == target).mean()))
+
+    out = E.audio_retrieval(model, tok, proc, cfg, eval_split="test", load_audio_fn=proc.load, batch_size=3, verbose=False)   # (3)
+    _, at_idx, ta_idx = retrieval.audio_retrieval_scores(A, T, k=10)
+    ref_at = retrieval.compute_retrieval_metric(at_idx, all_audio, all_text, gt_at)
+    ref_ta = retrieval.compute_retrieval_metric(ta_idx, all_text, all_audio, gt_ta, "ta")
+    for name in ("R1", "R5", "R10", "mAP10"):
+        assert out["audio_to_text"][name] == ref_at[name] and len(ref_at[name]) == len(all_audio), name
+        assert out["text_to_audio"][name] == ref_ta[name] and len(ref_ta[name]) == len(all_text), name
+    L64 = T64 @ A64.T
+    for dev_idx, M in ((at_idx, L64.T), (ta_idx, L64)):
+        dev_idx = dev_idx.cpu().numpy()
+        k = dev_idx.shape[1]
+        host_sorted = -np.sort(-M, axis=1)[:, :k]
+        assert dev_idx.min() >= 0
+        assert np.abs(np.take_along_axis(M, dev_idx.astype(np.int64), axis=1) - host_sorted).max() < 1e-5

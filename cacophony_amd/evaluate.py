@@ -1,6 +1,6 @@
 """The evaluation drivers that sit on the hot path in the reference, under the reference's names and argument meaning
 (the starred `@no_grad` wrappers of src/eval/eval_caco_torch.py:231-261 and their callers
-`compute_all_class_embeddings :265`, `zs_classification :289`, `audio_retrieval :343`).
+`compute_all_class_embeddings :265`, `zs_classification :289`, `audio_retrieval :343`, `audio_captioning :475`).
 
 The reference walks a dataset one file at a time: load, log-mel on the host, one forward at batch 1, one `@` per
 clip, and a full argsort of the final matrix on the host.  Here the same results come out of batches: clips of
@@ -15,6 +15,8 @@ Dataset processors and audio decoding are not part of this package: `dataprocess
 """
 from __future__ import annotations
 
+import csv
+import os
 from typing import Callable, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -174,3 +176,41 @@ def audio_retrieval(model, tokenizer, dataprocessor, datasetconfig: DatasetConfi
         print("text to audio retrieval:")
     ta = retrieval.compute_retrieval_metric(ta_idx, all_text, all_audio, gt_text_audio, "ta", verbose)
     return {"audio_to_text": at, "text_to_audio": ta}
+
+
+def audio_captioning(model, tokenizer, dataprocessor, datasetconfig: DatasetConfig, device=None, eval_split: str = "test",
+                     output_dir: str = "./", *, load_audio_fn: Optional[Callable] = None, batch_size: int = 32,
+                     max_decode_length: int = 100, temperature: float = 0.1, greedy: bool = False,
+                     generator: Optional[torch.Generator] = None, verbose: bool = True) -> Dict[str, object]:
+    """Audio captioning (eval_caco_torch.py:475-541): a caption per clip of the split, written with the references to
+    `predictions.csv` / `gt.csv` in the reference's layout (commas removed from the references, five reference columns).
+    The reference decodes one clip at a time through a full-prefix loop; here `batch_size` ragged clips decode together
+    through the key / value-cached decoder (`captioning.decode_caption_ids`: per-row stop, temperature sampling as in
+    `decode_caption` :459-461, or `greedy=True`).  Returns the paths and the lists that were written."""
+    from . import captioning
+    load = load_audio_fn or load_audio
+    filepaths, descriptions, _ = dataprocessor.get_filepaths_and_descriptions(current_split=eval_split)
+    names = [audio_name_of(fp) for fp in filepaths]
+    predicted: List[str] = []
+    for lo, hi in _chunks(len(filepaths), batch_size):
+        clips = [np.asarray(load(fp, dataprocessor.config.sampling_rate), dtype=np.float32) for fp in filepaths[lo:hi]]
+        batch = frontend.prepare_audio_batch(clips, datasetconfig, device)
+        ids = captioning.decode_caption_ids(model, batch, max_decode_length, temperature, tokenizer.bos_token_id,
+                                            tokenizer.eos_token_id, tokenizer.pad_token_id, greedy, generator)
+        predicted.extend(t.strip() for t in tokenizer.batch_decode(ids, skip_special_tokens=True))
+    references = [[d.replace(",", "") for d in descriptions[n]["description"]] for n in names]
+    assert len(predicted) == len(references)
+    pred_path, gt_path = os.path.join(output_dir, "predictions.csv"), os.path.join(output_dir, "gt.csv")
+    with open(pred_path, "w", newline="") as fp:
+        w = csv.writer(fp)
+        w.writerow(["file_name", "caption_predicted"])
+        w.writerows([n, c] for n, c in zip(names, predicted))
+    with open(gt_path, "w", newline="") as fg:
+        w = csv.writer(fg)
+        w.writerow(["file_name"] + [f"caption_reference_{i:02d}" for i in range(1, 6)])
+        for n, refs in zip(names, references):
+            w.writerow([n] + refs + [""] * max(0, 5 - len(refs)))
+    if verbose:
+        print(f"Predictions saved to {pred_path}")
+        print(f"Ground truth saved to {gt_path}")
+    return {"predictions_path": pred_path, "gt_path": gt_path, "file_names": names, "predicted": predicted, "references": references}

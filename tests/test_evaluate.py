@@ -189,6 +189,43 @@ def test_drivers_flow_on_cpu_stand_ins(monkeypatch):
     assert emb.shape == (2, 16) and torch.allclose(emb[1:], one)
 
 
+def test_audio_captioning_writes_the_reference_csv_layout(monkeypatch, tmp_path):
+    """audio_captioning (eval_caco_torch.py:475-541) with the decoder replaced by a stand-in: batches of ragged clips go
+    to the decoding loop with the tokenizer's special ids and the reference's defaults (100 tokens, temperature 0.1), and
+    the two CSV files have the reference's header, comma-free references and five reference columns."""
+    from cacophony_amd import captioning
+    _install_cpu_stand_ins(monkeypatch)
+    proc, _ = _toy_dataset(n_clips=4)
+    proc.descriptions["clip01"]["description"] = ["rain, heavy", "rain on a roof, then thunder"]
+    calls = []
+
+    def decode_caption_ids(model, audio_batch, max_decode_length=100, temperature=0.1, bos_id=0, eos_id=2, pad_id=1, greedy=False,
+                           generator=None, use_cache=True):
+        n = audio_batch["audio_patches"].shape[0]
+        calls.append((n, max_decode_length, temperature, bos_id, eos_id, pad_id, greedy))
+        base = len(calls) * 10
+        return torch.tensor([[bos_id, 50 + base + i, eos_id] for i in range(n)])
+
+    class Tok(StubTokenizer):
+        bos_token_id, eos_token_id, pad_token_id = 0, 2, 1
+
+        def batch_decode(self, ids, skip_special_tokens=False):
+            assert skip_special_tokens
+            return [f"  caption {int(r[1])} " for r in ids]
+
+    monkeypatch.setattr(captioning, "decode_caption_ids", decode_caption_ids)
+    out = E.audio_captioning(object(), Tok(), proc, C.DatasetConfig(patches_seq_len=500), eval_split="test", output_dir=str(tmp_path),
+                             load_audio_fn=proc.load, batch_size=3, verbose=False)
+    assert calls == [(3, 100, 0.1, 0, 2, 1, False), (1, 100, 0.1, 0, 2, 1, False)]
+    assert out["predicted"] == ["caption 60", "caption 61", "caption 62", "caption 70"]
+    pred = (tmp_path / "predictions.csv").read_text().splitlines()
+    gt = (tmp_path / "gt.csv").read_text().splitlines()
+    assert pred == ["file_name,caption_predicted", "clip00,caption 60", "clip01,caption 61", "clip02,caption 62", "clip03,caption 70"]
+    assert gt[0] == "file_name,caption_reference_01,caption_reference_02,caption_reference_03,caption_reference_04,caption_reference_05"
+    assert gt[2] == "clip01,rain heavy,rain on a roof then thunder,,,"
+    assert all(len(line.split(",")) == 6 for line in gt)
+
+
 # ----------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_drivers_on_the_device(tiny_state):

@@ -97,6 +97,37 @@ def load_audio(audio_path: str, dataset_sampling_rate: int) -> np.ndarray:
     return wav
 
 
+def load_caco_torch(ckpt_path: str, device=None, tokenizer=None, use_decoder: bool = False) -> Dict[str, object]:
+    """eval_caco_torch.py:154-178: {'model', 'tokenizer', 'device'} from a checkpoint file.  The file may be the torch
+    container (plain state dict or the `model_state_dict` / `state_dict` wrappers, :160-166) or the JAX side's Flax
+    msgpack file (cacophony_amd.checkpoint).  The reference downloads `roberta-base`'s tokenizer; offline that only works
+    from a local cache, so a tokenizer can be handed in."""
+    from .checkpoint import load_checkpoint
+    from .model import create_caco_model
+    model = create_caco_model(device=device, use_decoder=use_decoder).load_state_dict(load_checkpoint(ckpt_path))
+    if tokenizer is None:
+        from transformers import RobertaTokenizerFast
+        try:
+            tokenizer = RobertaTokenizerFast.from_pretrained("roberta-base", local_files_only=True)
+        except Exception as e:
+            raise RuntimeError("load_caco_torch: the `roberta-base` tokenizer is not in the local cache (no network here); "
+                               "pass tokenizer=...") from e
+    return {"model": model, "tokenizer": tokenizer, "device": model.device}
+
+
+def task_dataset_config(task: str) -> DatasetConfig:
+    """The DatasetConfig the reference's command line builds per task (eval_caco_torch.py:570-577, 605-613, 625-633):
+    'zs' = 10 s clips (500 patches), 'ar' / 'caption' = 30 s clips (1500 patches); 16 x 16 patches, 100 text tokens."""
+    if task == "zs":
+        patches = 100 * 10 * 8 // 16
+    elif task in ("ar", "caption"):
+        patches = 16000 * 30 * 8 // 160 // 16
+    else:
+        raise ValueError(f"task must be 'zs', 'ar' or 'caption', got {task!r}")
+    return DatasetConfig(batch_size=1, patches_seq_len=patches, time_patch_size=16, freq_patch_size=16, max_text_len=100,
+                         synthetic_prob=0.8)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # batched embedding of many items
 # ---------------------------------------------------------------------------------------------------------------------

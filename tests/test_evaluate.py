@@ -94,6 +94,16 @@ def test_wrappers_pass_the_reference_keywords():
     assert {k: v for k, v in seen["t"].items() if not k.startswith("text_")} == dict(deterministic=True, return_hidden_state=False, normalize=True)
 
 
+def test_task_configs_and_loader_contract(tmp_path):
+    assert E.task_dataset_config("zs").patches_seq_len == 500 and E.task_dataset_config("ar").patches_seq_len == 1500
+    assert E.task_dataset_config("caption") == E.task_dataset_config("ar") and E.task_dataset_config("zs").max_text_len == 100
+    with pytest.raises(ValueError):
+        E.task_dataset_config("asr")
+    if not torch.cuda.is_available():       # no CPU model: the loader fails loudly instead of returning something slower
+        with pytest.raises(RuntimeError):
+            E.load_caco_torch(str(tmp_path / "missing.ckpt"), tokenizer=StubTokenizer())
+
+
 def test_load_audio_without_decoder_says_so():
     with pytest.raises(ImportError, match="soundfile"):
         E.load_audio("/nonexistent.wav", 16000)

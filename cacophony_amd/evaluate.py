@@ -135,6 +135,8 @@ def embed_texts(model, tokenizer, texts: Sequence[str], max_text_len: int, devic
     """Normalised embeddings [len(texts), P].  Each string is tokenised on its own with padding to `max_text_len`
     (prepare_text_batch, eval_caco_torch.py:209-227), so the ids equal the reference's; the rows are then encoded
     `batch_size` at a time."""
+    if len(texts) == 0:
+        raise ValueError("embed_texts: no texts (empty split or class list)")
     out = []
     for lo, hi in _chunks(len(texts), batch_size):
         rows = [frontend.prepare_text_batch(t, tokenizer, max_text_len, device) for t in texts[lo:hi]]
@@ -167,6 +169,8 @@ def zs_classification(model, tokenizer, dataprocessor, datasetconfig: DatasetCon
     the hit test run on the device.  Returns the accuracy at ks[0] like the reference (and prints every k)."""
     load = load_audio_fn or load_audio
     filepaths, descriptions, _ = dataprocessor.get_filepaths_and_descriptions(current_split=subdir_name)
+    if len(filepaths) == 0:
+        raise ValueError(f"zs_classification: split {subdir_name!r} has no files")
     class_labels, class_to_index = class_index_map(descriptions)
     class_emb = compute_all_class_embeddings(model, tokenizer, class_labels, datasetconfig.max_text_len, device, prefix=text_prefix)
     targets = [class_to_index[descriptions[audio_name_of(fp)]["description"][0]] for fp in filepaths]
@@ -192,6 +196,8 @@ def audio_retrieval(model, tokenizer, dataprocessor, datasetconfig: DatasetConfi
     {"audio_to_text": {...}, "text_to_audio": {...}} as `compute_retrieval_metric` gives them."""
     load = load_audio_fn or load_audio
     filepaths, descriptions, _ = dataprocessor.get_filepaths_and_descriptions(current_split=eval_split)
+    if len(filepaths) == 0:
+        raise ValueError(f"audio_retrieval: split {eval_split!r} has no files")
     all_audio, all_text, gt_audio_text, gt_text_audio = retrieval_ground_truth(filepaths, descriptions)
     text_emb = embed_texts(model, tokenizer, all_text, datasetconfig.max_text_len, device)
     audio_emb = []

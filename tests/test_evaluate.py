@@ -99,6 +99,11 @@ def test_task_configs_and_loader_contract(tmp_path):
     assert E.task_dataset_config("caption") == E.task_dataset_config("ar") and E.task_dataset_config("zs").max_text_len == 100
     with pytest.raises(ValueError):
         E.task_dataset_config("asr")
+    empty = ToyProcessor({}, {})
+    with pytest.raises(ValueError, match="no files"):
+        E.zs_classification(object(), StubTokenizer(), empty, E.task_dataset_config("zs"), subdir_name="fold9", load_audio_fn=empty.load)
+    with pytest.raises(ValueError, match="no files"):
+        E.audio_retrieval(object(), StubTokenizer(), empty, E.task_dataset_config("ar"), load_audio_fn=empty.load)
     if not torch.cuda.is_available():       # no CPU model: the loader fails loudly instead of returning something slower
         with pytest.raises(RuntimeError):
             E.load_caco_torch(str(tmp_path / "missing.ckpt"), tokenizer=StubTokenizer())

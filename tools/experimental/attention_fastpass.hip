@@ -4,6 +4,9 @@
 // sums (2^60), and falls back to a full safe pass for the workgroup if any wave tripped the guard.  Removes ~22 of ~100
 // VALU instructions per 32-row block and 64-key tile on all but the first tile.  Cross-compiled for gfx950:
 // attention_kernel<96,false,4,2> 256 VGPRs, 13 spilled (prologue stores, 4 reloads per tile), the safe-only build 0 spills.
+// The algorithm (reference from tile 0, no maxima afterwards, 2^60 guard, redo through the maximum path) was checked in
+// NumPy against an exact float64 softmax on ramps (0.5 and 20 log2 units per tile), a +300 late spike, a dominant first
+// tile and all-very-negative rows: errors at the bf16-P level (<= 3.4e-3 on N(0,1) values), finite everywhere.
 // To try: cp tools/experimental/attention_fastpass.hip cacophony_amd/csrc/attention.hip ;
 //         tools/build_variant.sh fastpass attention.hip -DATTN_FAST_PASS ; CACO_LIB_PATH=... pytest -k attention ;
 //         tools/power_probe.py --attn

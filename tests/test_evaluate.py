@@ -242,18 +242,8 @@ def test_audio_captioning_writes_the_reference_csv_layout(monkeypatch, tmp_path)
 
 
 # ----------------------------------------------------------------------------------------------------------- GPU
-@pytest.mark.gpu
-def test_drivers_on_the_device(tiny_state):
-    """The batched drivers on the real front end, towers and device scoring.  A random-weight model maps every clip to
-    nearly the same embedding (cosines up to 0.99997, rank gaps down to 1e-6 in the oracle), so the checks are made
-    robust to near-ties: (1) a clip embedded in a ragged batch equals the clip embedded alone (the reference's way);
-    (2) the zero-shot accuracy equals a float64 host scoring of the same embeddings (top-1 margins are checked to be
-    far above fp32 noise); (3) the retrieval metrics are those of the device ranking of the same embeddings, lined up
-    with the right names, and that ranking agrees with a float64 host ranking value for value at every rank."""
-    from cacophony_amd.model import CACO
-    a, t, cc = C.tiny_configs(2)
-    assert t.vocab_size == TEXT_VOCAB
-    model = CACO(a, t, cc, device="cuda:0").load_state_dict(tiny_state)
+def _check_drivers(model, expect_cuda):
+    """Shared body of the device test and of its CPU dry run (same assertions on either backend)."""
     proc, _ = _toy_dataset()
     cfg = C.DatasetConfig(patches_seq_len=500, max_text_len=16)
     tok = StubTokenizer()
@@ -265,7 +255,8 @@ def test_drivers_on_the_device(tiny_state):
     A = torch.cat([E.embed_clips(model, clips[lo:hi], cfg) for lo, hi in E._chunks(len(clips), 3)], 0)
     T = E.embed_texts(model, tok, all_text, cfg.max_text_len)
     Cemb = E.compute_all_class_embeddings(model, tok, labels, cfg.max_text_len, prefix="This is a sound of ")
-    assert A.shape == (len(clips), 768) and T.shape == (len(all_text), 768) and Cemb.shape == (len(labels), 768) and A.is_cuda
+    assert A.shape == (len(clips), 768) and T.shape == (len(all_text), 768) and Cemb.shape == (len(labels), 768)
+    assert A.is_cuda == expect_cuda
     for i in (0, 3, 6):                                                 # (1) batch of three ragged clips vs batch of one
         alone = E.compute_audio_embedding(model, frontend.prepare_audio_batch([clips[i]], cfg))
         assert torch.nn.functional.cosine_similarity(alone, A[i:i + 1]).item() > 0.9999
@@ -292,3 +283,71 @@ def test_drivers_on_the_device(tiny_state):
         host_sorted = -np.sort(-M, axis=1)[:, :k]
         assert dev_idx.min() >= 0
         assert np.abs(np.take_along_axis(M, dev_idx.astype(np.int64), axis=1) - host_sorted).max() < 1e-5
+
+
+def test_device_test_body_dry_run_on_the_oracle(monkeypatch, tiny_state):
+    """The GPU case below, executed here with the oracle standing in for the library (front end, towers) and host code for
+    the scoring kernels: the assertions, shapes and bookkeeping of that test are exercised before it ever meets a GPU."""
+    from oracle import caco_oracle as O
+    a, t, cc = C.tiny_configs(2)
+    ref = O.CacoOracle(tiny_state, a, t, cc, backend="torch")
+
+    class OracleModel:
+        logit_scale = torch.tensor(float(cc.logit_scale_init_value))
+
+        def get_audio_embedding(self, audio_patches, audio_time_inds, audio_freq_inds, audio_mask, deterministic=True,
+                                return_hidden_state=True, normalize=False):
+            assert deterministic
+            with torch.no_grad():
+                out = ref.get_audio_embedding(audio_patches.numpy(), audio_time_inds.numpy(), audio_freq_inds.numpy(),
+                                              audio_mask.numpy(), return_hidden_state=return_hidden_state, normalize=normalize)
+            return torch.as_tensor(np.asarray(out)) if not return_hidden_state else tuple(torch.as_tensor(np.asarray(o)) for o in out)
+
+        def get_text_embedding(self, text_input_ids, text_mask, position_ids=None, deterministic=True, return_hidden_state=True,
+                               normalize=False):
+            assert deterministic and text_input_ids.dtype == torch.int64
+            with torch.no_grad():
+                out = ref.get_text_embedding(text_input_ids.numpy(), text_mask.numpy(), return_hidden_state=return_hidden_state,
+                                             normalize=normalize)
+            return torch.as_tensor(np.asarray(out)) if not return_hidden_state else tuple(torch.as_tensor(np.asarray(o)) for o in out)
+
+    def prepare_audio_batch(audio, datasetconfig, device=None, lengths=None):          # clip by clip, as the reference does
+        assert isinstance(audio, list)
+        outs = [O.prepare_audio_batch(np.asarray(c, np.float32)[None], datasetconfig.patches_seq_len, backend="torch") for c in audio]
+        return {k: torch.as_tensor(np.concatenate([o[k] for o in outs], 0)) for k in outs[0]}
+
+    def prepare_text_batch(text, tokenizer, max_text_len, device=None):
+        tok = tokenizer([text], padding="max_length", truncation=True, max_length=max_text_len, return_tensors="pt")
+        return {"text_input_ids": tok["input_ids"], "text_mask": tok["attention_mask"]}
+
+    def zs_scores(audio_emb, class_text_emb, target_idx, logit_scale=0.0, ks=(1,)):
+        order = torch.argsort(-(math.exp(logit_scale) * audio_emb @ class_text_emb.T), dim=-1, stable=True).numpy()
+        tgt = np.asarray(target_idx).reshape(-1)
+        return {str(int(k)): float((order[:, :int(k)] == tgt[:, None]).any(1).mean()) for k in ks}
+
+    def retrieval_scores(audio_emb, text_emb, k=10, sim=None):
+        logits = text_emb @ audio_emb.T
+        return (logits, torch.argsort(-logits.T, dim=-1, stable=True)[:, :k].to(torch.int32),
+                torch.argsort(-logits, dim=-1, stable=True)[:, :k].to(torch.int32))
+
+    monkeypatch.setattr(frontend, "prepare_audio_batch", prepare_audio_batch)
+    monkeypatch.setattr(frontend, "prepare_text_batch", prepare_text_batch)
+    monkeypatch.setattr(retrieval, "zs_classification_scores", zs_scores)
+    monkeypatch.setattr(retrieval, "audio_retrieval_scores", retrieval_scores)
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    _check_drivers(OracleModel(), expect_cuda=False)
+
+
+@pytest.mark.gpu
+def test_drivers_on_the_device(tiny_state):
+    """The batched drivers on the real front end, towers and device scoring.  A random-weight model maps every clip to
+    nearly the same embedding (cosines up to 0.99997, rank gaps down to 1e-6 in the oracle), so the checks are made
+    robust to near-ties: (1) a clip embedded in a ragged batch equals the clip embedded alone (the reference's way);
+    (2) the zero-shot accuracy equals a float64 host scoring of the same embeddings (top-1 margins are checked to be
+    far above fp32 noise); (3) the retrieval metrics are those of the device ranking of the same embeddings, lined up
+    with the right names, and that ranking agrees with a float64 host ranking value for value at every rank."""
+    from cacophony_amd.model import CACO
+    a, t, cc = C.tiny_configs(2)
+    assert t.vocab_size == TEXT_VOCAB
+    model = CACO(a, t, cc, device="cuda:0").load_state_dict(tiny_state)
+    _check_drivers(model, expect_cuda=True)

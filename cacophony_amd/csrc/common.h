@@ -12,6 +12,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CACO_WAVE 64
 
+// CACO_WAVE_LDS_SYNC(): lanes of ONE wave hand data to each other through LDS at this point (one lane's ds_write, another
+// lane's ds_read) with no workgroup barrier in between.  On the hardware a wave executes in lockstep and the compiler keeps
+// the program order of the may-alias LDS accesses, so in the product build the macro expands to NOTHING (the ISA is the
+// same with and without it); the functional simulator (tools/wavesim: a lane is a fiber) makes it a wave rendezvous.
+#ifdef WAVESIM
+#define CACO_WAVE_LDS_SYNC() wavesim_wave_sync()
+#else
+#define CACO_WAVE_LDS_SYNC() ((void)0)
+#endif
+
 namespace caco {
 
 // error plumbing shared by all translation units (defined in api.hip)

@@ -39,6 +39,7 @@ __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], c
         for (int r = 0; r < 4; ++r) o[r] = (bf16_t)epi_act<ACT>(v[r]);
         *reinterpret_cast<bf16x4*>(sc + lm * PITCH + (j * 16 + lg * 4) * 2) = o;
       }
+      CACO_WAVE_LDS_SYNC();
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {            // 8 rows x 128 B per store instruction
         const int row = tt * 8 + (lane >> 3), c16 = lane & 7;
@@ -46,6 +47,7 @@ __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], c
         const int64_t m = mw + i * 16 + row;
         if (m < p.M) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + m * p.ldc + nw + c16 * 8) = v;
       }
+      CACO_WAVE_LDS_SYNC();
     }
   } else if constexpr (EPI == EPI_F32) {
     constexpr int PITCH = 256;                    // 64 fp32; 16-byte chunk c of row r lives at chunk c ^ (r & 15)
@@ -58,6 +60,7 @@ __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], c
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<f32x4*>(sc + lm * PITCH + (((j * 4 + lg) ^ lm) << 4)) = acc[i][j] + b4[j];
+      CACO_WAVE_LDS_SYNC();
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {            // 4 rows x 256 B per store instruction
         const int row = tt * 4 + (lane >> 4), c4 = lane & 15;
@@ -69,6 +72,7 @@ __device__ __forceinline__ void wave_epilogue_128x64(const f32x4 (&acc)[8][4], c
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o) = v;
         }
       }
+      CACO_WAVE_LDS_SYNC();
     }
   }
 }

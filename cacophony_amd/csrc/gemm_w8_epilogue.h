@@ -111,12 +111,14 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
           *reinterpret_cast<bf16x4*>(slab + row * 128 + (((jb * 2 + (lq >> 1)) ^ ((row >> 1) & 7)) << 4) + (lq & 1) * 8) = o;
         }
       }
+      CACO_WAVE_LDS_SYNC();
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
         __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, W8_ST_AUX);
       }
+      CACO_WAVE_LDS_SYNC();
     }
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs; the residual of slab s+1 is fetched while slab s is processed
     const int rowb = p.ldc * 4;
@@ -156,6 +158,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
           const int row = ib * 16 + l16;
           *reinterpret_cast<f32x4*>(slab + row * 128 + (((jb * 4 + lq) ^ ((row >> 1) & 7)) << 4)) = v;
         }
+      CACO_WAVE_LDS_SYNC();
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
@@ -175,6 +178,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
           if (j == 0) { st1[i][tt] = a1; st2[i][tt] = a2; } else { st1[i][tt] += a1; st2[i][tt] += a2; }
         }
       }
+      CACO_WAVE_LDS_SYNC();
     }
     if (produce_st) {
       const int nslot = p.N >> 6, slot = nw >> 6;

@@ -1,0 +1,312 @@
+"""The kernel SOURCES of cacophony_amd/csrc executed on the CPU by the wavesim functional model (tools/wavesim), through
+the same C ABI and against the same checkers as tests/test_gpu_ops.py / test_gpu_model.py, at CPU-friendly sizes.
+
+What this is: a check of the kernels' index arithmetic - MFMA fragment layouts, LDS swizzles, LDS-DMA addressing, counted
+s_waitcnt vmcnt (LDS-DMA data lands only at the covering wait), transpose reads, buffer-descriptor range checks, masks,
+tile-boundary handling - that needs no GPU.  What it is NOT: hardware evidence (the `-m gpu` suite is), a timing, or a
+path the product can take (cacophony_amd never loads the simulator library).
+The model is pinned the other way round as well: the kernels it executes here passed the GPU suite on MI355X in rounds
+1 and 2, so a wrong instruction model would show up as a failure of a known-good kernel.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import simlib
+from tests.conftest import cosine_rows, load_golden, rel_l2
+
+pytestmark = pytest.mark.skipif(not simlib.available(), reason="no host clang++ for the wavesim build")
+
+from cacophony_amd import config as C  # noqa: E402
+from cacophony_amd import synth  # noqa: E402
+from oracle import caco_oracle as O  # noqa: E402
+
+P = simlib.ptr
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return simlib.load()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize("tile", [128, 2256, 8256])
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 128, 0), (520, 768, 256, 1), (257, 512, 192, 2), (64, 256, 64, 0)])
+def test_gemm_bf16(sim, tile, M, N, K, act):
+    assert sim.caco_set_gemm_tile(tile) == tile
+    a = _rand((M, K), 1).bfloat16()
+    w = _rand((N, K), 2, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 3)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, act, P(out), None))
+    ref = a.float() @ w.float().T + bias
+    ref = torch.nn.functional.silu(ref) if act == 1 else torch.nn.functional.gelu(ref) if act == 2 else ref
+    err = (out.float() - ref).abs()
+    assert torch.isfinite(out.float()).all()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2e-3).all(), f"max err {err.max().item():.4g}"
+    sim.caco_set_gemm_tile(256)
+
+
+@pytest.mark.parametrize("tile", [128, 2256, 8256])
+def test_gemm_f32_residual_in_place_and_plain(sim, tile):
+    sim.caco_set_gemm_tile(tile)
+    M, N, K = 301, 768, 192
+    a = _rand((M, K), 4).bfloat16()
+    w = _rand((N, K), 5, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 6)
+    x = _rand((M, N), 7)
+    ref = a.float() @ w.float().T + bias + x
+    simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(x), None))
+    assert (x - ref).abs().max().item() < 1e-4
+    out = torch.empty(M, N)
+    simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), None, None, M, N, K, P(out), None))
+    assert (out - a.float() @ w.float().T).abs().max().item() < 1e-4
+    sim.caco_set_gemm_tile(256)
+
+
+@pytest.mark.parametrize("kind", ["f32r", "bf16", "silu"])
+def test_gemm_w8_persistent_multi_tile_pipeline(sim, kind):
+    """More output tiles than workgroups (the simulator reports 16 CUs): operand loads prefetched across output-tile
+    boundaries, the counted wait that leaves an epilogue's stores in flight, a ragged last M tile in mid-pipeline."""
+    sim.caco_set_gemm_tile(8256)
+    M, N, K = 1900, 768, 256          # 8 x 3 = 24 tiles on 16 workgroups
+    a = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 13)
+    ref = a.float() @ w.float().T + bias
+    if kind == "f32r":
+        x0 = _rand((M, N), 14)
+        x = x0.clone()
+        simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(x), None))
+        assert (x - (ref + x0)).abs().max().item() < 1e-4
+    else:
+        act = 1 if kind == "silu" else 0
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+        simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, act, P(out), None))
+        r = torch.nn.functional.silu(ref) if act else ref
+        assert ((out.float() - r).abs() / (r.abs() + 1.0)).max().item() < 1e-2
+    sim.caco_set_gemm_tile(256)
+
+
+def test_gemm_rejects_bad_shapes(sim):
+    a = torch.zeros(64, 100, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        simlib.check(sim.caco_op_gemm_bf16(P(a), P(a), None, 64, 128, 100, 0, P(a), None))
+
+
+def test_layernorm(sim):
+    rows, dim = 203, 768
+    x = _rand((rows, dim), 11, 3.0) + 0.7
+    g, b = _rand((dim,), 12), _rand((dim,), 13)
+    of = torch.empty_like(x)
+    ob = torch.empty(rows, dim, dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_layernorm(P(x), P(g), P(b), rows, dim, 1e-5, P(of), P(ob), None))
+    ref = torch.nn.functional.layer_norm(x, (dim,), g, b, 1e-5)
+    assert (of - ref).abs().max().item() < 2e-5
+    assert (ob.float() - ref).abs().max().item() < 0.04
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attention_ref(q, k, v, key_mask, heads, hd, causal):
+    B, Sq, H = q.shape
+    S = k.shape[1]
+    qf = q.float().reshape(B, Sq, heads, hd).transpose(1, 2)
+    kf = k.float().reshape(B, S, heads, hd).transpose(1, 2)
+    vf = v.float().reshape(B, S, heads, hd).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) / math.sqrt(hd)
+    allow = torch.ones(B, 1, Sq, S, dtype=torch.bool)
+    if key_mask is not None:
+        allow = allow & (key_mask != 0)[:, None, None, :]
+    if causal:
+        allow = allow & torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    s = s.masked_fill(~allow, float("-inf"))
+    return (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B, Sq, H)
+
+
+@pytest.mark.parametrize("B,S,heads,hd,causal,valid", [
+    (2, 200, 2, 96, 0, [196, 77]),      # two query blocks per wave (S > 128), ragged last tile, key padding
+    (3, 32, 3, 64, 1, [32, 12, 1]),     # the text tower's shape: causal AND padding
+    (1, 496, 1, 96, 0, [496]),          # the audio tower's sequence length
+    (2, 100, 2, 64, 1, [100, 37]), (1, 64, 2, 96, 0, [64]), (1, 130, 1, 96, 1, [129])])
+def test_attention(sim, B, S, heads, hd, causal, valid):
+    H = heads * hd
+    qk = _rand((B, S, 2 * H), 20, 1.5).bfloat16()
+    v = _rand((B, S, H), 21).bfloat16()
+    mask = torch.zeros(B, S)
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    qkv = torch.cat([qk, v], -1).contiguous()
+    out = torch.full((B, S, H), float("nan"), dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_attention(P(qkv), 3 * H, H, 2 * H, P(mask), B, S, heads, hd, causal, P(out), None))
+    ref = _attention_ref(qk[..., :H], qk[..., H:], v, mask, heads, hd, bool(causal))
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < 0.03
+    simlib.check(sim.caco_op_attention(P(qkv), 3 * H, H, 2 * H, None, B, S, heads, hd, causal, P(out), None))
+    ref = _attention_ref(qk[..., :H], qk[..., H:], v, None, heads, hd, bool(causal))
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("B,Sq,S,heads,hd,valid", [(2, 32, 200, 2, 64, [196, 44]), (2, 1, 100, 2, 64, [100, 7]), (1, 200, 33, 1, 96, [33])])
+def test_cross_attention(sim, B, Sq, S, heads, hd, valid):
+    H = heads * hd
+    q = _rand((B, Sq, H), 40, 1.5).bfloat16()
+    kv = _rand((B, S, 2 * H), 41, 1.2).bfloat16()
+    mask = torch.zeros(B, S)
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, P(mask), B, S, heads, hd, 0, P(out), None))
+    ref = _attention_ref(q, kv[..., :H], kv[..., H:], mask, heads, hd, False)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("slope", [0.5, 3.0])
+def test_attention_lazy_reference_ramp(sim, slope):
+    """tests/test_gpu_ops.py::test_attention_lazy_reference_ramp on one head: scores that climb with the key index walk
+    the lazy exponent reference through many tiles, in the two-block and in the one-block kernel."""
+    B, S, heads, hd = 1, 500, 1, 96
+    H = heads * hd
+    qk = _rand((B, S, 2 * H), 40, 0.3)
+    qk[:, :, 0] += 4.0
+    ramp = torch.arange(S, dtype=torch.float32) / 64.0
+    qk[:, :, H] += slope * ramp[None, :] * (math.sqrt(hd) * math.log(2.0) / 4.0)
+    qk = qk.bfloat16()
+    v = _rand((B, S, H), 41).bfloat16()
+    qkv = torch.cat([qk, v], -1).contiguous()
+    ref = _attention_ref(qk[..., :H], qk[..., H:], v, None, heads, hd, False)
+    for Sq in (S, 100):
+        out = torch.empty(B, Sq, H, dtype=torch.bfloat16)
+        q = qkv[:, :Sq, :H].contiguous()
+        simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(qkv), 3 * H, H, 2 * H, None, B, S, heads, hd, 0, P(out), None))
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - ref[:, :Sq]).abs().max().item() < 0.03, (slope, Sq)
+
+
+# ------------------------------------------------------------------------------------------------ front end
+def _mel_patches(sim, wav, max_p, dtype=torch.float32, lengths=None):
+    wav = torch.as_tensor(wav).float().contiguous()
+    B, n = wav.shape
+    patches = torch.full((B, max_p, 256), float("nan"), dtype=dtype)
+    tinds, finds, mask = torch.empty(B, max_p), torch.empty(B, max_p), torch.empty(B, max_p)
+    dt = 1 if dtype == torch.bfloat16 else 0
+    lens = None if lengths is None else torch.as_tensor(lengths).long().contiguous()
+    simlib.check(sim.caco_mel_patches_lens(P(wav), P(lens), B, n, max_p, 0.2, 0.9, P(patches), dt, P(tinds), P(finds), P(mask), None))
+    return {"audio_patches": patches, "audio_time_inds": tinds, "audio_freq_inds": finds, "audio_mask": mask}
+
+
+def test_mel_spectrogram_matches_reference_golden(sim):
+    g = load_golden("mel.npz")
+    wav = torch.from_numpy(synth.make_waveforms(2))
+    frames = int(sim.caco_mel_num_frames(wav.shape[1]))
+    mel = torch.empty(2, frames, 128)
+    simlib.check(sim.caco_mel_spectrogram(P(wav), 2, wav.shape[1], 0.2, 0.9, P(mel), None))
+    mel = mel.numpy()
+    assert mel.shape == (2, 1000, 128)
+    assert np.abs(mel[0] - g["mel0"]).max() < 1e-3
+    assert np.abs(mel[1] - g["mel1"].astype(np.float32)).max() < 3e-3
+    assert np.allclose(mel[0][:, 0], math.log(1e-5) * 0.2 + 0.9, atol=1e-5)          # empty HTK filter, SURVEY Q13
+
+
+@pytest.mark.parametrize("tag,n,max_p", [("short", 12345, 64), ("tiny", 700, 16), ("3s", 48000, 500), ("trunc", 48000, 100)])
+def test_mel_ragged_lengths(sim, tag, n, max_p):
+    g = load_golden("mel.npz")
+    w = synth.make_waveform(7, n_samples=n)[None]
+    for dt, tol in ((torch.float32, 3e-3), (torch.bfloat16, 2e-2)):
+        p = _mel_patches(sim, w, max_p, dt)
+        for k in ("audio_time_inds", "audio_freq_inds", "audio_mask"):
+            np.testing.assert_array_equal(p[k][0].numpy(), g[f"{tag}_{k}"])
+        assert np.abs(p["audio_patches"][0].float().numpy() - g[f"{tag}_audio_patches"].astype(np.float32)).max() < tol
+
+
+def test_mel_per_clip_lengths_in_one_batch(sim):
+    n = 48000
+    lens = [48000, 20000, 7000]
+    wav = np.zeros((3, n), np.float32)
+    for i, L in enumerate(lens):
+        wav[i, :L] = synth.make_waveform(30 + i, n_samples=L)
+    p = _mel_patches(sim, wav, 150, lengths=lens)
+    for i, L in enumerate(lens):
+        ref = O.prepare_audio_batch(wav[i:i + 1, :L], 150)
+        for k in ("audio_time_inds", "audio_freq_inds", "audio_mask"):
+            np.testing.assert_array_equal(p[k][i].numpy(), ref[k][0])
+        nv = int(ref["audio_mask"].sum())
+        assert np.abs(p["audio_patches"][i, :nv].numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3
+        assert (p["audio_patches"][i, nv:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ scoring
+def test_similarity_normalize_topk(sim):
+    a, t = _rand((37, 768), 40), _rand((300, 768), 41)
+    an, tn = torch.empty_like(a), torch.empty_like(t)
+    simlib.check(sim.caco_l2_normalize(P(a), 37, 768, P(an), None))
+    simlib.check(sim.caco_l2_normalize(P(t), 300, 768, P(tn), None))
+    assert np.abs(an.numpy() - O.l2_normalize(O.get_ops("numpy"), a.numpy())).max() < 1e-6
+    out = torch.empty(37, 300)
+    simlib.check(sim.caco_similarity(P(an), 37, P(tn), 300, 768, 14.28, P(out), 300, None))
+    ref = 14.28 * (an.double() @ tn.double().T)
+    assert (out.double() - ref).abs().max().item() < 1e-4
+    idx = torch.empty(37, 10, dtype=torch.int32)
+    val = torch.empty(37, 10)
+    simlib.check(sim.caco_topk(P(out), 37, 300, 300, 1, 10, P(idx), P(val), None))
+    rv, ri = torch.sort(out, dim=1, descending=True, stable=True)
+    np.testing.assert_array_equal(idx.numpy(), ri[:, :10].numpy())
+    np.testing.assert_array_equal(val.numpy(), rv[:, :10].numpy())
+
+
+# ------------------------------------------------------------------------------------------------ whole towers
+@pytest.mark.parametrize("ln_fold", [0, 1], ids=["ln_pass", "ln_folded"])
+def test_tiny_config_matches_reference_golden(sim, tiny_state, ln_fold):
+    """tests/test_gpu_model.py::test_tiny_config_matches_reference_golden on the simulator: 2-layer full-width towers,
+    2 clips + 2 captions, against the outputs of the REFERENCE itself (tests/golden/caco_tiny.npz)."""
+    g = load_golden("caco_tiny.npz")
+    a, t, cc = C.tiny_configs(2)
+    m = simlib.SimModel(a, t, cc).load_state_dict(tiny_state)
+    assert m.set_ln_fold(ln_fold) == ln_fold
+    wav = synth.make_waveforms(2)
+    ab = _mel_patches(sim, wav, 500)
+    rows = g["probe_rows"]
+    a_emb, a_hid = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"])
+    a_hid = a_hid.numpy()
+    valid = rows[rows < 496]
+    sel = np.isin(rows, valid)
+    assert rel_l2(a_hid[:, valid], g["audio_hidden_rows"][:, sel]) < 1e-2
+    assert cosine_rows(a_emb.numpy(), g["audio_emb"]).min() > 0.999
+    assert rel_l2(a_emb.numpy(), g["audio_emb"]) < 1e-2
+    ids, tmask = synth.make_captions(2, 32, 1024)
+    t_emb, t_hid = m.text_forward(ids, tmask)
+    keep = tmask.astype(bool)
+    assert rel_l2(t_hid.numpy()[keep], g["text_hidden"][keep]) < 1e-2
+    assert cosine_rows(t_emb.numpy(), g["text_emb"]).min() > 0.999
+    a_n, _ = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
+    t_n, _ = m.text_forward(ids, tmask, normalize=True)
+    np.testing.assert_allclose(a_n.norm(dim=1).numpy(), 1.0, atol=1e-3)
+    assert cosine_rows(a_n.numpy(), g["audio_emb_norm"]).min() > 0.999
+    assert cosine_rows(t_n.numpy(), g["text_emb_norm"]).min() > 0.999
+    sim_at = torch.empty(2, 2)
+    scale = float(np.exp(2.6592))
+    simlib.check(sim.caco_similarity(P(a_n), 2, P(t_n), 2, 768, scale, P(sim_at), 2, None))
+    assert np.abs(sim_at.numpy() - g["at_logits"]).max() < 1e-3 * scale
+    pos = np.broadcast_to(np.arange(32) + 2, (2, 32)).copy()
+    t_pos, _ = m.text_forward(ids, tmask, position_ids=pos)
+    assert cosine_rows(t_pos.numpy(), g["text_emb_pos2"]).min() > 0.999
+
+
+def test_encode_audio_and_text_vs_oracle(sim, tiny_state):
+    """wav -> embedding (mel kernel, bf16 patches, towers, pooling, normalise) against the oracle's fp32 path."""
+    a, t, cc = C.tiny_configs(2)
+    m = simlib.SimModel(a, t, cc).load_state_dict(tiny_state)
+    o = O.CacoOracle(tiny_state, a, t, cc, backend="torch")
+    wav = synth.make_waveforms(2, start=60)
+    ids, tmask = synth.make_captions(2, 32, 1024, start=60)
+    ea, et = m.encode_audio(wav), m.encode_text(ids, tmask)
+    ra, rt = o.encode_audio(wav), o.encode_text(ids, tmask)
+    assert cosine_rows(ea.numpy(), ra).min() > 0.999
+    assert cosine_rows(et.numpy(), rt).min() > 0.999

@@ -1,0 +1,111 @@
+"""Build tools/wavesim/libcaco_sim.so: the kernel sources of cacophony_amd/csrc compiled for x86 against the wavesim
+functional model (wavesim.h) instead of hipcc / gfx950.  Same C ABI as libcaco_hip.so (include/caco_hip.h), "device"
+pointers are host pointers.  TEST INFRASTRUCTURE: used by tests/test_wavesim*.py (CPU) only.
+
+    python tools/wavesim/build_sim.py [--force] [--asan] [--extra file.hip ...]
+
+Source translation (the only edits made to a kernel source; everything else is the file as hipcc sees it):
+  * `asm volatile("s_waitcnt ..." ::: "memory")`           -> wavesim::s_waitcnt("...")
+  * `asm volatile("s_waitcnt vmcnt(%0) ..." :: "n"(E) ...)` -> wavesim::s_waitcnt_n("...", E)
+  * `extern __shared__ ... T NAME[];`                       -> T* NAME = (T*)wavesim::dyn_lds();
+  * `__attribute__((amdgpu_...(...)))` on kernels           -> dropped (occupancy hints)
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(REPO, "cacophony_amd", "csrc")
+INCLUDE = os.path.join(REPO, "include")
+GEN = os.path.join(HERE, "_gen")
+SHIM = os.path.join(HERE, "shim")
+LIB = os.path.join(HERE, "libcaco_sim.so")
+SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w8.hip", "attention.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
+CXX = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-O2", "-g1", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-ffp-contract=off",
+         "-Wno-unknown-attributes", "-Wno-unused-value", "-Wno-ignored-attributes", "-Wno-c++20-extensions",
+         "-Wno-macro-redefined", "-Wno-pass-failed", "-x", "c++"]
+
+_ASM = re.compile(r'asm\s+volatile\s*\(\s*"(s_waitcnt[^"]*)"\s*(.*?)\)\s*;')
+_EXT = re.compile(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(char|float|int)\s+(\w+)\s*\[\s*\]\s*;')
+
+
+def translate(text: str) -> str:
+    def asm(m):
+        body, ops = m.group(1), m.group(2)
+        n = re.search(r'"n"\s*\((.*)\)\s*:\s*"memory"', ops)
+        if "%0" in body:
+            if not n:
+                raise ValueError(f"cannot translate asm operands: {m.group(0)}")
+            return f'wavesim::s_waitcnt_n("{body}", {n.group(1)});'
+        return f'wavesim::s_waitcnt("{body}");'
+    text = _ASM.sub(asm, text)
+    text = re.sub(r"__attribute__\(\(amdgpu_[a-z_]+\([^)]*\)\)\)", "", text)      # kernel-only attributes
+    text = _EXT.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(wavesim::dyn_lds());", text)
+    left = [l for l in text.splitlines() if re.search(r"\basm\s+volatile", l) and '""' not in l]
+    if left:
+        raise ValueError("untranslated inline asm:\n" + "\n".join(left))
+    return text
+
+
+def _newer(out, deps):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
+
+
+def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, verbose: bool = True) -> str:
+    os.makedirs(GEN, exist_ok=True)
+    os.makedirs(os.path.join(SHIM, "hip"), exist_ok=True)
+    shim = os.path.join(SHIM, "hip", "hip_runtime.h")
+    if not os.path.exists(shim):
+        with open(shim, "w") as f:
+            f.write('// stands in for <hip/hip_runtime.h> in the wavesim build\n#pragma once\n#include "wavesim.h"\n')
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
+        os.path.join(HERE, "wavesim.h"), os.path.join(INCLUDE, "caco_hip.h"), os.path.abspath(__file__)]
+    flags = FLAGS + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
+    tag = ".asan" if asan else ""
+
+    def one(src):
+        path = src if os.path.isabs(src) else os.path.join(CSRC, src)
+        base = os.path.basename(path)
+        obj = os.path.join(GEN, base.replace(".hip", tag + ".o").replace(".cpp", tag + ".o"))
+        if not force and _newer(obj, [path] + headers):
+            return obj
+        gen = os.path.join(GEN, base.replace(".hip", ".cpp"))
+        if base.endswith(".hip"):
+            with open(path) as f:
+                t = translate(f.read())
+            with open(gen, "w") as f:
+                f.write(f'#line 1 "{path}"\n' + t)
+        else:
+            gen = path
+        cmd = [CXX, *flags, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{base}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            sys.stderr.write(r.stderr)
+        return obj
+
+    srcs = list(SOURCES) + list(extra) + [os.path.join(HERE, "wavesim.cpp")]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, srcs))
+    if force or not _newer(lib, objs):
+        cmd = [CXX, "-shared", "-fPIC", "-o", lib, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else [])
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[wavesim] linked {lib}")
+    return lib
+
+
+if __name__ == "__main__":
+    extra = []
+    if "--extra" in sys.argv:
+        extra = sys.argv[sys.argv.index("--extra") + 1:]
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv, extra=extra)

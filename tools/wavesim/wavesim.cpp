@@ -1,0 +1,251 @@
+// wavesim runtime: lane fibers, the wave / workgroup rendezvous scheduler, the grid launcher and the host-API stand-ins.
+// See wavesim.h.  Test infrastructure only.
+#include "wavesim.h"
+
+#include <stdarg.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// ---- context switch (x86-64 SysV): saves the callee-saved registers on the current stack, swaps stack pointers ----------
+extern "C" void wavesim_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl wavesim_switch
+.type wavesim_switch,@function
+wavesim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size wavesim_switch,.-wavesim_switch
+)");
+
+namespace wavesim {
+
+WAVESIM_TLS Lane* cur = nullptr;
+WAVESIM_TLS idx3 block_idx = {0, 0, 0}, block_dim = {1, 1, 1}, grid_dim = {1, 1, 1};
+int dma_late = [] { const char* e = getenv("WAVESIM_DMA"); return (e && !strcmp(e, "eager")) ? 0 : 1; }();
+
+namespace {
+
+constexpr size_t STACK_BYTES = 256 * 1024;
+constexpr int MAX_THREADS = 1024;
+constexpr size_t DYN_LDS = 160 * 1024;
+
+struct Worker {                 // per OS thread: fiber stacks, lane / wave records, the dynamic LDS block
+  char* stacks = nullptr;
+  Lane* lanes = nullptr;
+  Wave* waves = nullptr;
+  char* lds = nullptr;
+  void* main_sp = nullptr;
+  const std::function<void()>* body = nullptr;
+  ~Worker() {
+    if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
+    free(lanes);
+    free(waves);
+    free(lds);
+  }
+  void ensure() {
+    if (stacks) return;
+    stacks = (char*)mmap(nullptr, STACK_BYTES * MAX_THREADS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == MAP_FAILED) fail("mmap of fiber stacks failed");
+    lanes = (Lane*)calloc(MAX_THREADS, sizeof(Lane));
+    waves = (Wave*)aligned_alloc(64, sizeof(Wave) * (MAX_THREADS / 64));
+    lds = (char*)aligned_alloc(256, DYN_LDS);
+    memset(lds, 0, DYN_LDS);
+  }
+};
+Worker g_workers[65];                 // slot 0: the launching thread itself; never torn down (reused by every launch)
+WAVESIM_TLS Worker* tl_w = &g_workers[0];
+
+void lane_entry() {
+  Worker& W = *tl_w;
+  (*W.body)();
+  Lane* L = cur;
+  L->state = 3;
+  while (L->vm_count) vm_retire_one(L);     // outstanding DMA still lands (nobody can observe it any more)
+  wavesim_switch(&L->sp, W.main_sp);
+  fail("resumed a finished lane");
+}
+
+void yield_to_scheduler() {
+  Lane* L = cur;
+  wavesim_switch(&L->sp, tl_w->main_sp);
+}
+
+void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& body) {
+  Worker& W = *tl_w;
+  W.ensure();
+  W.body = &body;
+  block_idx = bidx;
+  block_dim = bdim;
+  grid_dim = gdim;
+  const int nthreads = (int)(bdim.x * bdim.y * bdim.z);
+  if (nthreads > MAX_THREADS || nthreads <= 0) fail("workgroup of %d threads", nthreads);
+  const int nwaves = (nthreads + 63) / 64;
+  for (int w = 0; w < nwaves; ++w) {
+    W.waves[w].nlanes = 0;
+    W.waves[w].gen = 0;
+  }
+  for (int t = 0; t < nthreads; ++t) {
+    Lane& L = W.lanes[t];
+    L.stack = W.stacks + (size_t)t * STACK_BYTES;
+    L.tid.x = (unsigned)t % bdim.x;
+    L.tid.y = ((unsigned)t / bdim.x) % bdim.y;
+    L.tid.z = (unsigned)t / (bdim.x * bdim.y);
+    L.lane = t & 63;
+    L.state = 0;
+    L.site = nullptr;
+    L.wave = &W.waves[t >> 6];
+    L.vm_head = L.vm_count = 0;
+    L.wave->lanes[L.lane] = &L;
+    L.wave->nlanes = L.lane + 1;
+    // initial frame: six callee-saved registers, then the entry address, then a pad so that the entry sees rsp % 16 == 8
+    uintptr_t top = ((uintptr_t)L.stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** f = reinterpret_cast<void**>(top);
+    f[-1] = nullptr;
+    f[-2] = reinterpret_cast<void*>(&lane_entry);
+    for (int i = 3; i <= 8; ++i) f[-i] = nullptr;
+    L.sp = &f[-8];
+  }
+  int live = nthreads;
+  while (live > 0) {
+    bool progress = false;
+    int at_barrier = 0;
+    live = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      Wave& wv = W.waves[w];
+      for (;;) {
+        for (int l = 0; l < wv.nlanes; ++l) {
+          Lane* L = wv.lanes[l];
+          while (L->state == 0) {
+            cur = L;
+            wavesim_switch(&W.main_sp, L->sp);
+            progress = true;
+          }
+        }
+        int n_op = 0, n_bar = 0;
+        const void* site = nullptr;
+        bool same = true;
+        for (int l = 0; l < wv.nlanes; ++l) {
+          Lane* L = wv.lanes[l];
+          if (L->state == 1) {
+            if (n_op++ == 0) site = L->site;
+            else same = same && site == L->site;
+          } else if (L->state == 2) ++n_bar;
+        }
+        if (n_op == 0) { at_barrier += n_bar; live += n_bar; break; }
+        if (n_bar) fail("block (%u,%u,%u) wave %d: %d lanes wait at a wave operation while %d wait at the workgroup barrier", bidx.x, bidx.y, bidx.z, w, n_op, n_bar);
+        if (!same) fail("block (%u,%u,%u) wave %d: lanes arrived at different wave-operation call sites (divergent control flow around a cross-lane operation)", bidx.x, bidx.y, bidx.z, w);
+        unsigned long long act = 0;
+        for (int l = 0; l < wv.nlanes; ++l)
+          if (wv.lanes[l]->state == 1) { wv.lanes[l]->state = 0; act |= 1ull << l; }
+        wv.active[wv.gen & 1] = act;
+        ++wv.gen;
+      }
+    }
+    if (at_barrier > 0) {
+      for (int t = 0; t < nthreads; ++t)
+        if (W.lanes[t].state == 2) W.lanes[t].state = 0;
+      progress = true;
+    }
+    if (!progress && live > 0) fail("deadlock in block (%u,%u,%u)", bidx.x, bidx.y, bidx.z);
+  }
+  cur = nullptr;
+}
+
+}  // namespace
+
+void wave_rendezvous(const void* site) {
+  Lane* L = cur;
+  L->site = site;
+  L->state = 1;
+  yield_to_scheduler();
+}
+
+void block_barrier() {
+  cur->state = 2;
+  yield_to_scheduler();
+}
+
+char* dyn_lds() { return tl_w->lds; }
+
+void s_waitcnt(const char* text) {
+  const char* p = strstr(text, "vmcnt(");
+  if (p) vm_wait(atoi(p + 6));
+}
+
+void fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "[wavesim] ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  abort();
+}
+
+void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body) {
+  if (lds_bytes > DYN_LDS) fail("launch with %zu bytes of dynamic LDS", lds_bytes);
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  static const int max_threads = [] {
+    const char* e = getenv("WAVESIM_THREADS");
+    int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+  }();
+  const int nthr = (int)std::min<long>(max_threads, nblocks);
+  std::atomic<long> next{0};
+  auto work = [&](int slot) {
+    tl_w = &g_workers[slot];
+    for (;;) {
+      const long b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      idx3 bi;
+      bi.x = (unsigned)(b % grid.x);
+      bi.y = (unsigned)((b / grid.x) % grid.y);
+      bi.z = (unsigned)(b / ((long)grid.x * grid.y));
+      run_block(bi, block, grid, body);
+    }
+  };
+  static std::mutex launch_mu;           // one launch at a time: the worker slots are shared
+  std::lock_guard<std::mutex> lk(launch_mu);
+  if (nthr <= 1) { work(0); return; }
+  std::vector<std::thread> pool;
+  for (int i = 0; i < nthr; ++i) pool.emplace_back(work, i + 1);
+  for (auto& t : pool) t.join();
+}
+
+}  // namespace wavesim
+
+// ---- host API stand-ins ------------------------------------------------------------------------------------------------
+hipError_t hipMalloc(void** p, size_t bytes) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, bytes ? bytes : 1)) return hipErrorOutOfMemory;
+  *p = q;
+  return hipSuccess;
+}
+hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  const char* e = getenv("WAVESIM_CUS");
+  p->multiProcessorCount = e ? atoi(e) : 16;
+  snprintf(p->name, sizeof(p->name), "wavesim (gfx950 functional model)");
+  return hipSuccess;
+}

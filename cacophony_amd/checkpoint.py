@@ -302,14 +302,25 @@ def state_dict_to_flax(state: Mapping[str, object], audio_heads: int = 8, scan: 
     return tree
 
 
-def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
-    """Either container -> state dict with the torch key names.  torch files: `model_state_dict` / `state_dict` wrappers are
-    unwrapped (eval_caco_torch.py:160-166); anything else is read as a Flax msgpack file."""
-    try:
-        import torch
-        obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+def checkpoint_format(path: str) -> str:
+    """'torch' for a torch.save file (zip container, or the legacy pickle stream: 0x80 + protocol 2..5), 'flax' otherwise
+    (a msgpack map starts 0x81..0x8f / 0xde / 0xdf).  The container is sniffed, not guessed from a failed load."""
+    with open(path, "rb") as f:
+        head = f.read(4)
+    if head[:4] == b"PK\x03\x04" or (len(head) >= 2 and head[0] == 0x80 and 2 <= head[1] <= 5):
+        return "torch"
+    return "flax"
+
+
+def load_checkpoint(path: str, weights_only: bool = True) -> Dict[str, np.ndarray]:
+    """Either container -> state dict with the torch key names.  torch files (`checkpoint_format`) go through torch.load -
+    its errors surface as they are; `weights_only=False` is the reference's plain torch.load (eval_caco_torch.py:158) for
+    files that pickle more than tensors - and the `model_state_dict` / `state_dict` wrappers are unwrapped (:160-166);
+    anything else is read as a Flax msgpack file."""
+    if checkpoint_format(path) == "flax":
         return flax_to_state_dict(read_flax_msgpack(path))
+    import torch
+    obj = torch.load(path, map_location="cpu", weights_only=weights_only)
     for key in ("model_state_dict", "state_dict"):
         if isinstance(obj, Mapping) and key in obj and isinstance(obj[key], Mapping):
             obj = obj[key]

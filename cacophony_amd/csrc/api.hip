@@ -634,7 +634,8 @@ int caco_create(const caco_config* cfg, caco_model** out) {
     CACO_REQUIRE(cfg->audio_hidden % 128 == 0 && cfg->audio_intermediate % 128 == 0 && cfg->patch_size % 128 == 0,
                  "caco_create: audio hidden/intermediate/patch sizes must be multiples of 128");
     CACO_REQUIRE(cfg->audio_heads > 0 && cfg->audio_hidden % cfg->audio_heads == 0, "caco_create: bad audio head count");
-    CACO_REQUIRE(cfg->pool_heads > 0 && cfg->audio_hidden % cfg->pool_heads == 0, "caco_create: bad pool head count");
+    CACO_REQUIRE(cfg->pool_heads > 0 && cfg->audio_hidden % cfg->pool_heads == 0 && (cfg->pool_heads == 1 || cfg->pool_heads % 2 == 0),
+                 "caco_create: the audio pooler takes 1 or an even number of heads dividing the hidden size (got %d)", cfg->pool_heads);
     CACO_REQUIRE(cfg->projection_size % 8 == 0, "caco_create: projection_size must be a multiple of 8");
   }
   if (cfg->has_text) {
@@ -795,7 +796,6 @@ static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype,
   AudioWs w;
   w.plan(A, M, batch, seq, H, c.audio_intermediate);
   const size_t o_pb = A.reserve((size_t)M * P * 2);
-  const size_t o_hid = A.reserve((size_t)M * H * 4);
   const size_t o_pool = A.reserve((size_t)batch * c.pool_heads * H * 4);
   const size_t o_pv = A.reserve((size_t)batch * H * 4);
   const size_t o_emb = A.reserve((size_t)batch * c.projection_size * 4);
@@ -808,8 +808,8 @@ static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype,
   CACO_STAGE("audio.patch_embed", linear_f32(m->enc.input_proj, pb, M, nullptr, x, st));
   CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, c.num_freq_patches, st));
   CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
-  float* hid = hidden ? hidden : A.at<float>(o_hid);
-  CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hid, h, st));
+  // the fp32 hidden states are only written when the caller asks for them (encode_audio does not: 390 MB per batch of 256)
+  CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hidden, h, st));
   // AudioAttentionPooler.forward, caco.py:41-79 (projections folded out of the token loop, pool.hip)
   float* pooled = A.at<float>(o_pool);                  // [B, heads, H]: softmax-weighted token means per head
   float* pv = A.at<float>(o_pv);                        // [B, H]: value projection of the pooled rows, heads concatenated

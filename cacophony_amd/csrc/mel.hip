@@ -10,10 +10,12 @@
 // 128 HTK mel filters over 257 bins (:94-103), log(x + 1e-5) * scale + bias (:104).
 //
 // One workgroup = 256 threads = 16 consecutive frames (= one row of 8 patches) x 16 threads per
-// frame.  The 512-point real FFT is a 256-point complex FFT of the even/odd packed frame, done as
-// two register-resident radix-16 passes with one transposition through LDS, then the real-input
-// split.  The Hann window, the FFT twiddles and the mel filterbank (CSR: 506 non-zero weights) are
-// staged in LDS once per workgroup.  fp32 throughout.
+// frame; it is persistent over several 16-frame blocks.  The 512-point real FFT is a 256-point complex
+// FFT of the even/odd packed frame, done as two register-resident radix-16 passes with one
+// transposition through LDS, then the real-input split.  Everything that does not change from block to
+// block lives in REGISTERS for the life of the workgroup: the thread's 28 Hann taps, its 30 W256
+// twiddles, its 38 mel filter weights and 8 filter starts (since round 2; round 1 staged them in LDS);
+// only the W512 twiddles of the real-input split are staged in LDS, once per workgroup.  fp32 throughout.
 #include <math.h>
 #include <vector>
 
@@ -120,16 +122,19 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
   const int tid = threadIdx.x, fl = tid >> 4, t = tid & 15;
   const int b = blockIdx.y;
   const float* w = wav + (int64_t)b * n_samples;
+  int64_t n_valid = n_samples;          // samples past this bound read as the STFT's zero padding (:78)
   if constexpr (MODE != MEL_NATURAL_F32) {
     // ---- patch bookkeeping of spectrogram_to_patches (eval_caco_torch.py:132-144), done by the same launch --------------
     // lengths != null: clip b holds lengths[b] real samples (the rest of its row is zero padding): its spectrogram has
     // ceil(len / 160) frames and only the patches of those frames are valid - what the reference gets by running
-    // prepare_audio_batch (:181-206) clip by clip.  The mel values of the frames it does have are the same either way: the
-    // STFT pads with zeros (:78).  Rows [valid, S) of the patch tensor are zero, their indices 0, their mask 0.
+    // prepare_audio_batch (:181-206) clip by clip: the sample fetch is bounded by lengths[b], so the tail frames see the
+    // STFT's zero padding (:78) whatever the row holds past the clip (a clip cut out of a longer buffer, say).
+    // Rows [valid, S) of the patch tensor are zero, their indices 0, their mask 0.
     constexpr int nfreq = NMEL / 16;
     if (lengths) {
       int64_t len = lengths[b];
       len = len < 0 ? 0 : (len > n_samples ? n_samples : len);
+      n_valid = len;                    // whatever the caller's buffer holds past lengths[b] is not part of the clip
       const int64_t full_b = ((len + HOP - 1) / HOP / FPB) * nfreq;
       if (full_b < rows_out) rows_out = (int)full_b;
       const int nblk_b = (rows_out + nfreq - 1) / nfreq;
@@ -181,11 +186,11 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (i < SPAN / 4) {
         const int64_t g = g0 + 4 * i;
-        if (vec_ok && g + 3 < n_samples) {
+        if (vec_ok && g + 3 < n_valid) {
           v = *reinterpret_cast<const f32x4*>(w + g);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (g + r < n_samples) ? w[g + r] : 0.f;   // zero pad, :78
+          for (int r = 0; r < 4; ++r) v[r] = (g + r < n_valid) ? w[g + r] : 0.f;     // zero pad, :78
         }
       }
       pf[r3] = v;

@@ -23,7 +23,7 @@ constexpr int PMAXC = 4;         // bf16x4 chunks per lane -> hidden <= 1024
 template <int HEADS>
 __global__ __launch_bounds__(PW * 64) void pool_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wq,
                                                             const float* __restrict__ mask, int S, int H,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int out_heads) {
   extern __shared__ __attribute__((aligned(16))) float sm[];      // [PW][HEADS][H] partial sums, then [PW][HEADS][2] (m, l)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(PW * 64) void pool_rows_kernel(const bf16_t* __rest
         num += part[((int64_t)wv * HEADS + h) * H + k] * f;
       }
     }
-    out[((int64_t)b * HEADS + h) * H + k] = den > 0.f ? num / den : 0.f;
+    out[((int64_t)b * out_heads + h) * H + k] = den > 0.f ? num / den : 0.f;       // out_heads: heads per clip in `out`
   }
 }
 
@@ -149,16 +149,21 @@ __global__ __launch_bounds__(256) void token_group_mean_kernel(const float* __re
 int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,
                    hipStream_t st) {
   CACO_REQUIRE(x && wq && out && batch > 0 && seq > 0, "attn_pool: bad arguments");
-  CACO_REQUIRE(heads == 1 || heads == 2, "attn_pool: %d pooling heads unsupported (1 or 2)", heads);
+  CACO_REQUIRE(heads == 1 || heads % 2 == 0, "attn_pool: %d pooling heads unsupported (1 or an even number)", heads);
   CACO_REQUIRE(hidden % 4 == 0 && hidden <= 256 * PMAXC, "attn_pool: hidden %d must be a multiple of 4, <= %d", hidden, 256 * PMAXC);
-  const size_t smem = (size_t)PW * heads * (hidden + 2) * sizeof(float);
+  // two heads per launch (the register budget of one pass over the rows); more heads - the JAX checkpoints pool with 8,
+  // src/caco/load_model.py:46 - take heads / 2 passes, each writing its head pair of the [batch, heads, hidden] output
+  const int per = heads == 1 ? 1 : 2;
+  const size_t smem = (size_t)PW * per * (hidden + 2) * sizeof(float);
   CACO_REQUIRE(smem <= 160 * 1024, "attn_pool: hidden %d too large for the LDS combine buffer", hidden);
   if (heads == 1) {
     CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<1>), 160 * 1024, nullptr));
-    hipLaunchKernelGGL(pool_rows_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
+    hipLaunchKernelGGL(pool_rows_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out, 1);
   } else {
     CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<2>), 160 * 1024, nullptr));
-    hipLaunchKernelGGL(pool_rows_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out);
+    for (int h0 = 0; h0 < heads; h0 += 2)
+      hipLaunchKernelGGL(pool_rows_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, wq + (size_t)h0 * hidden, mask, seq, hidden,
+                         out + (size_t)h0 * hidden, heads);
   }
   return check_hip(hipGetLastError(), "attn_pool launch");
 }

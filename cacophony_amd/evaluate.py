@@ -97,14 +97,34 @@ def load_audio(audio_path: str, dataset_sampling_rate: int) -> np.ndarray:
     return wav
 
 
-def load_caco_torch(ckpt_path: str, device=None, tokenizer=None, use_decoder: bool = False) -> Dict[str, object]:
+def load_caco_torch(ckpt_path: str, device=None, tokenizer=None, use_decoder: bool = False, caco_config=None,
+                    audio_config=None, weights_only: bool = True) -> Dict[str, object]:
     """eval_caco_torch.py:154-178: {'model', 'tokenizer', 'device'} from a checkpoint file.  The file may be the torch
     container (plain state dict or the `model_state_dict` / `state_dict` wrappers, :160-166) or the JAX side's Flax
-    msgpack file (cacophony_amd.checkpoint).  The reference downloads `roberta-base`'s tokenizer; offline that only works
-    from a local cache, so a tokenizer can be handed in."""
-    from .checkpoint import load_checkpoint
-    from .model import create_caco_model
-    model = create_caco_model(device=device, use_decoder=use_decoder).load_state_dict(load_checkpoint(ckpt_path))
+    msgpack file (cacophony_amd.checkpoint).
+
+    The two sides of the reference disagree on two hyper-parameters that do not change a single tensor shape (SURVEY Q5 /
+    Q6): the torch model pools the audio tokens with 2 heads and LayerNorm eps 1e-5 (caco.py:20,294; mae.py:68,76,123), the
+    JAX model the Flax file comes from with 8 heads (src/caco/load_model.py:46) and Flax's eps 1e-6 in the audio stack
+    (src/caco/audio_models/mae.py:87,93,137).  A Flax file is therefore loaded into a model built with the JAX side's
+    values unless `caco_config` / `audio_config` say otherwise; a torch file gets the torch defaults.
+    The reference downloads `roberta-base`'s tokenizer; offline that only works from a local cache, so one can be passed."""
+    from dataclasses import replace
+    from .checkpoint import checkpoint_format, load_checkpoint
+    from .config import default_audio_config, default_caco_config, default_text_config
+    from .model import CACO
+    if not torch.cuda.is_available():       # before the file is even opened: there is no CPU model to load it into
+        raise RuntimeError("cacophony_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+    if checkpoint_format(ckpt_path) == "flax":
+        if caco_config is None:
+            caco_config = replace(default_caco_config(), num_attention_pool_heads=8)
+        if audio_config is None:
+            audio_config = replace(default_audio_config(), layer_norm_eps=1e-6)
+    caco_config = caco_config if caco_config is not None else default_caco_config()
+    audio_config = audio_config if audio_config is not None else default_audio_config()
+    dec = replace(default_text_config(), num_hidden_layers=4) if use_decoder else None          # caco.py:297-309
+    model = CACO(audio_config, default_text_config(), caco_config, decoder_config=dec, device=device)
+    model.load_state_dict(load_checkpoint(ckpt_path, weights_only=weights_only))
     if tokenizer is None:
         from transformers import RobertaTokenizerFast
         try:

@@ -58,6 +58,10 @@ class _HipModel:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         if self.device.type != "cuda":
             raise RuntimeError(f"cacophony_amd runs on MI355X only, got device '{self.device}'")
+        if self.device.index is None:
+            # 'cuda' / torch.device('cuda') (the reference CLI's idiom) means the current device; tensors allocated on it
+            # report an index, and torch.device('cuda') != torch.device('cuda:0'), so the index is resolved once, here
+            self.device = torch.device("cuda", torch.cuda.current_device())
         cfg = _lib.CacoConfigC()
         self._lib.caco_default_config(C.byref(cfg))
         a, t = audio_config, text_config
@@ -319,11 +323,17 @@ class CACO(_HipModel):
         if wav.dim() == 1:
             wav = wav[None]
         B = wav.shape[0]
+        text_input_ids = _dev_tensor(text_input_ids, torch.int64, self.device, "text_input_ids")    # lists / arrays as well
+        text_mask = _dev_tensor(text_mask, torch.int64, self.device, "text_mask")
+        if text_input_ids.dim() != 2 or text_input_ids.shape != text_mask.shape:
+            raise ValueError(f"text_input_ids / text_mask must both be [B, T], got {tuple(text_input_ids.shape)} / {tuple(text_mask.shape)}")
         Bt = int(text_input_ids.shape[0])
         P = self.caco_config.projection_size
         if packed and Bt != B:
             raise ValueError(f"encode_pairs(packed=True) needs as many captions as clips, got {Bt} vs {B}")
         lens = None if lengths is None else _dev_tensor(lengths, torch.int64, self.device, "lengths")
+        if lens is not None and tuple(lens.shape) != (B,):
+            raise ValueError(f"lengths must be [{B}], got {tuple(lens.shape)}")
         n_split = max(1, min(int(audio_streams), B))
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()

@@ -79,6 +79,31 @@ def test_torch_container_and_wrappers(tmp_path):
         _assert_same({k: v.numpy() for k, v in sd.items()}, got)
 
 
+def test_container_is_sniffed_not_guessed(tmp_path):
+    """A torch file that torch.load rejects must fail as a torch file, not as an unrelated msgpack error, and a Flax file
+    must never be handed to the unpickler."""
+    import pytest
+    sd = _state(1, False)
+    fl, tz, legacy, broken = (str(tmp_path / n) for n in ("f.msgpack", "t.ckpt", "legacy.ckpt", "broken.ckpt"))
+    ck.write_flax_msgpack({"0": {"params": ck.state_dict_to_flax(sd)}}, fl)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tz)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, legacy, _use_new_zipfile_serialization=False)
+    assert ck.checkpoint_format(fl) == "flax" and ck.checkpoint_format(tz) == "torch" and ck.checkpoint_format(legacy) == "torch"
+    _assert_same(sd, ck.load_checkpoint(legacy))
+    with open(broken, "wb") as f:
+        f.write(b"PK\x03\x04" + b"\x00" * 64)
+    with pytest.raises(Exception) as ei:
+        ck.load_checkpoint(broken)
+    assert "msgpack" not in str(ei.value).lower() and "ExtType" not in str(ei.value)
+    # a checkpoint that pickles more than tensors: refused by default with torch's own message, loadable on request
+    rich = str(tmp_path / "rich.ckpt")
+    import argparse
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "args": argparse.Namespace(lr=1e-4)}, rich)
+    with pytest.raises(Exception, match="(?i)weights_only|unsupported global|Unpickl"):
+        ck.load_checkpoint(rich)
+    _assert_same(sd, ck.load_checkpoint(rich, weights_only=False))
+
+
 def test_attention_relayout_is_the_same_function():
     """Flax MHA from the tree (restated) == torch MultiheadAttention from the mapped packed weights, same inputs."""
     rng = np.random.default_rng(0)

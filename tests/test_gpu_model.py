@@ -459,3 +459,38 @@ def test_token_id_validation_and_device_guard(tiny_model):
     with pytest.raises(IndexError):
         tiny_model.get_text_embedding(ids, tmask, position_ids=np.full((2, 32), 10 ** 6))
     assert torch.isfinite(tiny_model.get_text_embedding(ids, tmask, return_hidden_state=False)).all()
+
+
+def test_jax_side_hyperparameters_8_pool_heads_eps_1e6(tiny_state):
+    """8 pooling heads and LayerNorm eps 1e-6 on the same tensor shapes (src/caco/load_model.py:46): what
+    evaluate.load_caco_torch builds for a Flax checkpoint.  Against the oracle, and distinguishable from the 2-head model."""
+    a, t, cc = C.tiny_configs(2)
+    a8, cc8 = replace(a, layer_norm_eps=1e-6), replace(cc, num_attention_pool_heads=8)
+    m = CACO(a8, t, cc8, device=DEV).load_state_dict(tiny_state)
+    o = O.CacoOracle(tiny_state, a8, t, cc8, backend="torch")
+    o2 = O.CacoOracle(tiny_state, a8, t, cc, backend="torch")
+    _, ab = _audio_batch(3, 500, start=5)
+    host = {k: v.cpu().numpy() for k, v in ab.items()}
+    args = (host["audio_patches"], host["audio_time_inds"], host["audio_freq_inds"], host["audio_mask"])
+    emb = m.get_audio_embedding(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"],
+                                return_hidden_state=False, normalize=True).cpu().numpy()
+    r8 = o.get_audio_embedding(*args, normalize=True)[0]
+    r2 = o2.get_audio_embedding(*args, normalize=True)[0]
+    assert cosine_rows(emb, r8).min() > COS_TOL
+    mu = r8.mean(0, keepdims=True)
+    assert cosine_rows(emb - mu, r8 - mu).min() > cosine_rows(emb - mu, r2 - mu).max()
+
+
+def test_unindexed_device_and_host_inputs_to_encode_pairs(tiny_state):
+    """device='cuda' (the reference CLI's idiom) resolves to the current device, so the `out=` views encode_pairs hands to
+    the towers compare equal to it; ids / masks may be lists or arrays."""
+    a, t, cc = C.tiny_configs(2)
+    m = CACO(a, t, cc, device="cuda").load_state_dict(tiny_state)
+    assert m.device.index is not None
+    wav = synth.make_waveforms(2, n_samples=32000)
+    ids, tmask = synth.make_captions(2, 32, 1024)
+    ea, et = m.encode_pairs(torch.from_numpy(wav), ids.tolist(), tmask.tolist())
+    ra, rt = m.encode_audio(wav), m.encode_text(ids, tmask)
+    assert torch.equal(ea, ra) and torch.equal(et, rt)
+    with pytest.raises(ValueError):
+        m.encode_pairs(torch.from_numpy(wav), ids, tmask, lengths=[32000])

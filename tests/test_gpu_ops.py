@@ -302,3 +302,17 @@ def test_similarity_and_normalize_exact_fp32():
     assert (sim.double() - ref).abs().max().item() < 1e-4
     z = l2_normalize(torch.zeros(2, 768, device=DEV))
     assert torch.isfinite(z).all() and (z == 0).all()
+
+
+def test_mel_lengths_bound_the_sample_fetch():
+    """A row that holds something else past lengths[b]: the tail frames see the STFT's zero padding, as when the reference
+    pre-processes that clip alone (same case as tests/test_wavesim.py runs on the simulator)."""
+    n = 24000
+    lens = [24000, 10100, 5130]            # 64 and 33 frames: the last used frames reach past the clip
+    wav = synth.make_waveform(50, n_samples=n)[None].repeat(3, 0).copy()
+    p = frontend.mel_patches_device(torch.from_numpy(wav).to(DEV), 80, torch.float32, lengths=lens)
+    for i, L in enumerate(lens):
+        ref = O.prepare_audio_batch(wav[i:i + 1, :L], 80)
+        np.testing.assert_array_equal(p["audio_mask"][i].cpu().numpy(), ref["audio_mask"][0])
+        nv = int(ref["audio_mask"].sum())
+        assert np.abs(p["audio_patches"][i, :nv].cpu().numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3

@@ -310,3 +310,40 @@ def test_encode_audio_and_text_vs_oracle(sim, tiny_state):
     ra, rt = o.encode_audio(wav), o.encode_text(ids, tmask)
     assert cosine_rows(ea.numpy(), ra).min() > 0.999
     assert cosine_rows(et.numpy(), rt).min() > 0.999
+
+
+def test_jax_side_hyperparameters_8_pool_heads_eps_1e6(sim, tiny_state):
+    """The JAX model pools with 8 heads and LayerNorm eps 1e-6 on the SAME tensor shapes (SURVEY Q5 / Q6,
+    src/caco/load_model.py:46): what evaluate.load_caco_torch builds for a Flax checkpoint.  Against the oracle, and
+    different from the 2-head model (a silent fall-back to 2 heads would pass a shape check)."""
+    from dataclasses import replace
+    a, t, cc = C.tiny_configs(2)
+    a8, cc8 = replace(a, layer_norm_eps=1e-6), replace(cc, num_attention_pool_heads=8)
+    m = simlib.SimModel(a8, None, cc8).load_state_dict({k: v for k, v in tiny_state.items() if not k.startswith(("text_", "logit"))})
+    o = O.CacoOracle(tiny_state, a8, t, cc8, backend="torch")
+    wav = synth.make_waveforms(2, n_samples=32000, start=5)
+    ab = _mel_patches(sim, wav, 100)
+    emb, hid = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
+    host = {k: v.numpy() for k, v in ab.items()}
+    r_emb, r_hid = o.get_audio_embedding(host["audio_patches"], host["audio_time_inds"], host["audio_freq_inds"], host["audio_mask"], normalize=True)
+    nv = int(host["audio_mask"][0].sum())
+    assert rel_l2(hid.numpy()[:, :nv], r_hid[:, :nv]) < 1e-2
+    assert cosine_rows(emb.numpy(), r_emb).min() > 0.999
+    o2 = O.CacoOracle(tiny_state, a8, t, cc, backend="torch")
+    r2, _ = o2.get_audio_embedding(host["audio_patches"], host["audio_time_inds"], host["audio_freq_inds"], host["audio_mask"], normalize=True)
+    mu = r_emb.mean(0, keepdims=True)
+    assert cosine_rows(emb.numpy() - mu, r_emb - mu).min() > cosine_rows(emb.numpy() - mu, r2 - mu).max()
+
+
+def test_mel_lengths_bound_the_sample_fetch(sim):
+    """A row that holds something else past lengths[b] (a clip cut out of a longer buffer): the tail frames must see the
+    STFT's zero padding, exactly as when the reference pre-processes that clip alone (mel.hip)."""
+    n = 24000
+    lens = [24000, 10100, 5130]          # 64 and 33 frames: the last used frames reach past the clip
+    wav = synth.make_waveform(50, n_samples=n)[None].repeat(3, 0).copy()       # every row full of signal
+    p = _mel_patches(sim, wav, 80, lengths=lens)
+    for i, L in enumerate(lens):
+        ref = O.prepare_audio_batch(wav[i:i + 1, :L], 80)
+        np.testing.assert_array_equal(p["audio_mask"][i].numpy(), ref["audio_mask"][0])
+        nv = int(ref["audio_mask"].sum())
+        assert np.abs(p["audio_patches"][i, :nv].numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3

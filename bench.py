@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line; it also carries
                   N = 1 only.
 
 CACO_BENCH_DRYRUN=1: no GPU, no library - the same control flow (warm-up, fences, timed loop, MAX all-reduce, teardown
-order) on the gloo backend with a stand-in step: tests/test_bench_dryrun.py runs it at world size 2.
+order) AND the same step closure (make_step: encode_pairs -> dist.gather_packed -> similarity into the row block) on the
+gloo backend with CPU stand-ins for the towers and the similarity kernel: tests/test_bench_dryrun.py runs it at world size 2.
 """
 from __future__ import annotations
 
@@ -223,6 +224,44 @@ def timed_loop(step, steps, warmup, world, sync, tensor_device):
     return elapsed
 
 
+def make_step(model, wav, ids, mask, sim_out, similarity_fn, gather_fn, audio_streams=1, check_sizes=False):
+    """THE step of the benchmark (also what the gloo dry run executes, with CPU stand-ins for `model` and `similarity_fn`):
+    both towers write one packed [B, 2, P] buffer = the all-gather payload (text tower on a side stream next to the audio
+    tower, one workspace per tower and stream inside the library), ONE all-gather, this rank's row block
+    sim_out[B, W*B] = A_local . T_all^T read through the banks' row strides.  No other device work in between.
+    `check_sizes` adds dist.gather_packed's shard-size check (one tiny all-reduce): off in the timed path, where every rank
+    holds B_PER_GPU rows by construction."""
+    def step():
+        bank = model.encode_pairs(wav, ids, mask, SEQ, audio_streams=audio_streams, packed=True)
+        allb = gather_fn(bank, check_sizes=check_sizes)
+        return similarity_fn(bank[:, 0], allb[:, 1], 1.0, out=sim_out)
+    return step
+
+
+class _DryrunModel:
+    """CPU stand-in with encode_pairs' contract (packed fp32 [B, 2, P] bank, rows L2-normalised, a function of the inputs
+    only), so that the dry run drives the real step closure and the real exchange; `delay` makes ranks unequally fast."""
+
+    def __init__(self, dim, delay):
+        self.dim, self.delay = dim, delay
+
+    def encode_pairs(self, wav, ids, mask, max_patches=None, audio_streams=1, packed=False):
+        time.sleep(self.delay)
+        B = wav.shape[0]
+        k = torch.arange(self.dim, dtype=torch.float32)[None, :]
+        ea = torch.cos(wav[:, :1] * (k + 1.0)) + wav[:, 1:2]
+        et = torch.sin((ids[:, :1].float() + mask.sum(1, keepdim=True).float()) * 0.01 * (k + 1.0))
+        bank = torch.stack([torch.nn.functional.normalize(ea, dim=1), torch.nn.functional.normalize(et, dim=1)], 1).contiguous()
+        assert packed and bank.shape == (B, 2, self.dim)
+        return bank
+
+
+def _dryrun_similarity(a, t, scale=1.0, out=None):
+    r = scale * a.double() @ t.double().T
+    out[:, :r.shape[1]].copy_(r)
+    return out
+
+
 def _timeit(fn, n, sync):
     fn()
     sync()
@@ -257,18 +296,24 @@ def main():
 
     lib = model = None
     state = None
+    check_sizes = os.environ.get("CACO_BENCH_CHECK_SIZES", "0") not in ("", "0")
     if DRYRUN:
+        # the REAL step closure and the REAL exchange (dist.gather_packed on the gloo backend); only the towers and the
+        # similarity kernel are CPU stand-ins.  CACO_BENCH_DRYRUN_UNEQUAL=1: rank 0 holds one row more than the others -
+        # with CACO_BENCH_CHECK_SIZES=1 the step must refuse that on every rank instead of hanging in the collective.
         device = torch.device("cpu")
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         sync = lambda: None
-        bank = torch.zeros(B_PER_GPU, 2, 8)
         from cacophony_amd.dist import gather_packed
-
-        def step():
-            time.sleep(0.002 * (1 + rank))                       # ranks of unequal speed: the MAX must win
-            allb = gather_packed(bank + rank)
-            return allb[:, 1].sum()
+        b_here = B_PER_GPU + (1 if (rank == 0 and os.environ.get("CACO_BENCH_DRYRUN_UNEQUAL", "0") not in ("", "0")) else 0)
+        g = torch.Generator().manual_seed(1000 + rank)
+        wav = torch.rand(b_here, 4, generator=g)
+        ids = torch.randint(3, 50265, (b_here, TEXT_LEN), generator=g)
+        mask = (torch.arange(TEXT_LEN)[None, :] < torch.randint(8, TEXT_LEN + 1, (b_here, 1), generator=g)).long()
+        sim_out = torch.zeros(b_here, world * B_PER_GPU, dtype=torch.float32)
+        model = _DryrunModel(8, 0.002 * (1 + rank))                # ranks of unequal speed: the MAX must win
+        step = make_step(model, wav, ids, mask, sim_out, _dryrun_similarity, gather_packed, args.audio_streams, check_sizes)
         finite = True
     else:
         if not torch.cuda.is_available():
@@ -287,19 +332,22 @@ def main():
         wav, ids, mask = _make_inputs(B_PER_GPU, rank, device)
         sim_out = torch.empty(B_PER_GPU, world * B_PER_GPU, dtype=torch.float32, device=device)
         sync = torch.cuda.synchronize
-
-        def step():
-            # text tower on a side stream next to the audio tower (one workspace per tower and stream inside the library);
-            # both write into one packed [B, 2, 768] buffer = the all-gather payload; no other device work in between
-            bank = model.encode_pairs(wav, ids, mask, SEQ, audio_streams=args.audio_streams, packed=True)
-            allb = gather_packed(bank)
-            return similarity(bank[:, 0], allb[:, 1], 1.0, out=sim_out)
+        step = make_step(model, wav, ids, mask, sim_out, similarity, gather_packed, args.audio_streams, check_sizes)
 
     elapsed = timed_loop(step, args.steps, args.warmup, world, sync, device)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B_PER_GPU * args.steps / elapsed
+    dry_err = None
     if not DRYRUN:
         finite = bool(torch.isfinite(sim_out).all().item())
+    else:
+        # what the closure left in sim_out must be this rank's row block of the global matrix, in rank order
+        bank = model.encode_pairs(wav, ids, mask, SEQ, packed=True)
+        parts = [torch.empty_like(bank) for _ in range(world)] if world > 1 else [bank]
+        if world > 1:
+            dist.all_gather(parts, bank)
+        ref = bank[:, 0].double() @ torch.cat([p[:, 1] for p in parts], 0).double().T
+        dry_err = float((sim_out.double() - ref).abs().max())
 
     # ---- per-launch-group timing with HIP events on the launch stream (separate, un-timed pass) -----------------
     stages, roofline, extra = {}, None, None
@@ -340,16 +388,18 @@ def main():
                                   "(tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
         except Exception:
             traffic = None
+        # algorithmic bytes of one fc1 launch: A [M,768] bf16 in + W [3072,768] bf16 in + out [M,3072] bf16
+        alg_bytes = B_PER_GPU * SEQ_RUN * H * 2 + I * H * 2 + B_PER_GPU * SEQ_RUN * I * 2
         if dom:
             roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [126976,768] x [3072,768]^T)",
                         "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],
-                        "note": "peak = nominal 2.4 GHz dense figure.  On random operands this kernel runs at the 1400 W socket power cap "
-                                "(shader clock ~1.9 of 2.4 GHz; the same instruction stream does 1.42 PFLOP/s on zero operands), as does the "
-                                "vendor library's GEMM on the same shape (hipBLASLt 1.17-1.19 PFLOP/s without bias / SiLU); the kernel uses "
-                                "v_mfma_f32_16x16x32_bf16 because it draws less power per FLOP than 32x32x16 (register-resident loops: 2.04 "
-                                "vs 1.82 PFLOP/s at the throttle point) - profiles/r2_v3/{power_probe,blaslt_calib,mfma_power}.txt, DESIGN.md 4"}
+                        "algorithmic_bytes_per_launch": alg_bytes,
+                        "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                        "note": "peak = the nominal dense bf16 MFMA figure of MI355X_MICROARCH.md; what bounds this kernel in "
+                                "practice (package power cap, vendor-library calibration) is DESIGN.md section 4 with the "
+                                "measurements under profiles/"}
 
         if not args.no_extra_configs:
             extra = {}
@@ -397,6 +447,8 @@ def main():
                        "gemm_tile": int(lib.caco_set_gemm_tile(0)) if lib is not None else None},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extra, "stages": stages, "outputs_finite": finite,
         }
+        if DRYRUN:
+            out["dryrun_row_block_max_err"] = dry_err
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()          # rank 0's un-timed passes are over: every rank tears the group down together

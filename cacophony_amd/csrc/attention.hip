@@ -376,6 +376,13 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   CACO_REQUIRE(head_dim == 64 || head_dim == 96, "attention: head_dim %d not in {64, 96}", head_dim);
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
+  // short sequences (the text tower at T = 32): one wave per (clip, head, query block), attention_small.hip.  Opt-in
+  // (CACO_ATTN_SMALL=1, read at every call) until it has been timed and verified on hardware.
+  {
+    const char* e = getenv("CACO_ATTN_SMALL");
+    if (e && atoi(e) != 0 && attention_small_ok(seq_q, seq, head_dim))
+      return attention_small(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, causal, out, st, kv_batch_rows);
+  }
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
   constexpr int NW = 4;
   // two query blocks per wave once the sequence fills the 256-row workgroups that makes; short sequences (text, decoder)

@@ -60,7 +60,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 
 // Tile order.  The n-tiles are processed in groups of G (p.ngroup): all M panels of one group, then the next group,
 // n fastest inside a group.  A group's weight rows (G x 256 x K bf16) then stay in the XCD's 4 MiB L2 for the whole
-// pass instead of being re-streamed through it once per M panel.  Off by default (launch_w8).
+// pass instead of being re-streamed through it once per M panel.  Default: groups of 4 at K <= 1024 (launch_w8).
 __device__ __forceinline__ void w4_decode(int t, int tiles_n, int tiles_m, int G, int& tm, int& tn) {
   const int per = tiles_m * G;
   const int g = t / per;                 // groups before the last one are full
@@ -325,11 +325,24 @@ int launch_w8(const GemmArgs& p, hipStream_t st) {
   const int cus = env_grid > 0 && env_grid < num_cu ? env_grid : num_cu;
   const int grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus / 8 * 8;
   GemmArgs q = p;
-  {   // n-tiles per L2 group.  Default: one group (n fastest over all of N).  Grouping was measured on the encoder
-      // shapes (CACO_W_NGROUP = 2..6): within +-2 % - the weight re-reads it removes are served by the Infinity Cache.
-    static const int env_g = getenv("CACO_W_NGROUP") ? atoi(getenv("CACO_W_NGROUP")) : 0;
+  {   // n-tiles per L2 group (w4_decode).  An XCD's 32 workgroups run 32 consecutive tiles at a time; with n fastest over
+      // all of N the weight rows they touch (N x K bf16: 4.7 MB for fc1) exceed the XCD's 4 MiB L2 and are re-streamed
+      // through it once per M panel.  Groups of 4 n-tiles at K <= 1024 keep the group's weights (1.5 MB) plus the eight
+      // A panels in flight (3.1 MB) resident: fabric reads of one fc1 launch 1.15 -> 0.81 GB by the TCC counters
+      // (profiles/r2_v3), time -0.5 %.  Bytes are what the power cap prices, so it is on by default since
+      // round 3; CACO_W_NGROUP=<n> forces a group width, CACO_W_NGROUP=0 restores one group (read at every launch).
+    const char* env = getenv("CACO_W_NGROUP");
+    const int env_g = env ? atoi(env) : -1;
     const int tiles_n = p.N / 256;
-    q.ngroup = (env_g > 0 && env_g < tiles_n) ? env_g : tiles_n;
+    int g = tiles_n;
+    if (tiles_n > 4 && p.K <= 1024) {           // equal groups where N allows: fc1 12 -> 3 x 4, QKV 9 -> 3 x 3
+      g = 4;
+      for (int d = 4; d >= 2; --d)
+        if (tiles_n % d == 0) { g = d; break; }
+    }
+    if (env_g == 0) g = tiles_n;
+    else if (env_g > 0) g = env_g < tiles_n ? env_g : tiles_n;
+    q.ngroup = g;
     // start-time spread of the workgroups (units of 1024 cycles): measured without effect (0 .. 128), the epilogue is not
     // HBM-bound; kept as an experiment switch
     static const int env_s = getenv("CACO_W8_STAGGER") ? atoi(getenv("CACO_W8_STAGGER")) : 0;

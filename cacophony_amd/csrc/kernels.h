@@ -76,6 +76,11 @@ int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
                   int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows = 0);
 
+// attention_small.hip: one wave per (clip, head, 32-query block) for seq_q, seq <= 64 at head_dim 64 (the text tower at T = 32)
+bool attention_small_ok(int seq_q, int seq, int head_dim);
+int attention_small(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
+                    int batch, int seq, int heads, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows);
+
 // pool.hip: learned-query attention pooling over the encoder output rows themselves (projections folded out):
 // x bf16 [B, S, H], wq fp32 [heads, H] -> out fp32 [B, heads, H]
 int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,

@@ -1,7 +1,9 @@
 """bench.py's multi-process control flow, executed before any 8-GPU driver run: warm-up, the (synchronize, barrier,
 synchronize) fences, the timed loop, the MAX all-reduce of the ranks' wall times, rank 0's single JSON line and the
-teardown order - on the gloo backend at world size 2 with a stand-in step (CACO_BENCH_DRYRUN=1: no GPU, no library).
-The per-rank step there is `gather_packed` on a [256, 2, 8] bank, i.e. the real exchange of the data-parallel path."""
+teardown order - on the gloo backend at world size 2 (CACO_BENCH_DRYRUN=1: no GPU, no library).
+The per-rank step is bench.make_step itself - encode_pairs(packed) -> dist.gather_packed -> similarity into this rank's
+row block - with CPU stand-ins for the towers and the similarity kernel only: the exchange, the strided views and the row
+block placement are the real ones, and the row block is checked against an independent all-gather."""
 import json
 import os
 import socket
@@ -17,9 +19,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd):
-    env = dict(os.environ, CACO_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+def _run(cmd, expect_failure=False, **extra_env):
+    env = dict(os.environ, CACO_BENCH_DRYRUN="1", OMP_NUM_THREADS="1", **extra_env)
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
+    if expect_failure:
+        return r
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0 only
@@ -35,6 +39,26 @@ def test_bench_control_flow_two_ranks_gloo():
     assert out["ms_per_step"] >= 3.9
     assert abs(out["value"] - 2 * 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
     assert out["data"].startswith("none")      # a dry run can never be mistaken for a measurement
+    assert out["dryrun_row_block_max_err"] < 1e-6      # the step closure left rank 0's [256, 512] row block in place
+
+
+def test_bench_step_closure_refuses_unequal_shards_on_every_rank():
+    """Rank 0 holds 257 rows, rank 1 holds 256: with the shard-size check on, bench.py's step (make_step ->
+    dist.gather_packed(check_sizes=True)) must raise on BOTH ranks - no hang inside all_gather_into_tensor, no corrupted
+    row block - and torchrun must report the failure."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+             expect_failure=True, CACO_BENCH_DRYRUN_UNEQUAL="1", CACO_BENCH_CHECK_SIZES="1")
+    assert r.returncode != 0
+    assert r.stderr.count("pad the shards to one size") >= 2, r.stderr[-3000:]      # one ValueError per rank
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]           # and no result line
+
+
+def test_bench_step_closure_with_size_check_on_equal_shards():
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+               CACO_BENCH_CHECK_SIZES="1")
+    assert out["n_gpus"] == 2 and out["dryrun_row_block_max_err"] < 1e-6
 
 
 def test_bench_control_flow_single_process():

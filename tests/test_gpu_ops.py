@@ -316,3 +316,42 @@ def test_mel_lengths_bound_the_sample_fetch():
         np.testing.assert_array_equal(p["audio_mask"][i].cpu().numpy(), ref["audio_mask"][0])
         nv = int(ref["audio_mask"].sum())
         assert np.abs(p["audio_patches"][i, :nv].cpu().numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3
+
+
+@pytest.mark.parametrize("B,Sq,S,heads,causal,valid", [
+    (256, 32, 32, 12, 1, None), (5, 32, 32, 3, 0, [32, 7, 20, 32, 1]), (2, 64, 64, 12, 1, [64, 33]), (2, 37, 37, 2, 1, [37, 5]),
+    (2, 20, 50, 12, 0, [50, 33]), (3, 1, 64, 12, 0, [64, 2, 1]), (1, 33, 33, 1, 0, [0])])
+def test_attention_small_kernel(lib, monkeypatch, B, Sq, S, heads, causal, valid):
+    """attention_small.hip (one wave per (clip, head, 32-query block); opt-in through CACO_ATTN_SMALL) against the torch
+    checker and against the big kernel.  Same cases as tests/test_wavesim.py, plus the text tower's batch."""
+    hd = 64
+    H = heads * hd
+    q = _rand((B, Sq, H), 50, 1.5).bfloat16()
+    kv = _rand((B, S, 2 * H), 51, 1.2).bfloat16()
+    mask = torch.zeros(B, S, device=DEV)
+    if valid is None:
+        valid = [1 + (7 * i) % S for i in range(B)]
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CACO_ATTN_SMALL", flag)
+        out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.check(lib.caco_op_attention_qkv(_p(q), H, Sq, _p(kv), 2 * H, 0, H, _p(mask), B, S, heads, hd, causal, _p(out), _st()))
+        torch.cuda.synchronize()
+        outs[flag] = out.float()
+    assert torch.isfinite(outs["1"]).all()
+    qf = q.float().view(B, Sq, heads, hd).transpose(1, 2)
+    kf = kv[..., :H].float().view(B, S, heads, hd).transpose(1, 2)
+    vf = kv[..., H:].float().view(B, S, heads, hd).transpose(1, 2)
+    sc = qf @ kf.transpose(-1, -2) / math.sqrt(hd)
+    allow = (mask != 0)[:, None, None, :].expand(B, 1, Sq, S)
+    if causal:
+        allow = allow & torch.tril(torch.ones(S, S, dtype=torch.bool, device=DEV))[None, None]
+    sc = sc.masked_fill(~allow, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).transpose(1, 2).reshape(B, Sq, H)
+    live = torch.isfinite(ref).all(-1)
+    if live.any():
+        assert (outs["1"][live] - ref[live]).abs().max().item() < 0.03
+    assert (outs["1"][~live] == 0).all()
+    assert (outs["1"] - outs["0"]).abs().max().item() < 0.02

@@ -347,3 +347,65 @@ def test_mel_lengths_bound_the_sample_fetch(sim):
         np.testing.assert_array_equal(p["audio_mask"][i].numpy(), ref["audio_mask"][0])
         nv = int(ref["audio_mask"].sum())
         assert np.abs(p["audio_patches"][i, :nv].numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3
+
+
+@pytest.mark.parametrize("ngroup", ["0", "2", "4", None])
+def test_gemm_w8_n_tile_groups(sim, ngroup, monkeypatch):
+    """The persistent kernel's tile order in groups of n-tiles (w4_decode; default since round 3: groups of 3-4 at
+    K <= 1024): equal groups, a ragged last group (5 n-tiles in groups of 2 / 4), one group; both cursors (operand
+    prefetch and epilogue) must decode the same order."""
+    if ngroup is None:
+        monkeypatch.delenv("CACO_W_NGROUP", raising=False)
+    else:
+        monkeypatch.setenv("CACO_W_NGROUP", ngroup)
+    sim.caco_set_gemm_tile(8256)
+    for (M, N, K) in ((700, 1280, 128), (520, 2304, 64)):      # 3 x 5 and 3 x 9 tiles
+        a = _rand((M, K), 1).bfloat16()
+        w = _rand((N, K), 2, 1.0 / math.sqrt(K)).bfloat16()
+        bias = _rand((N,), 3)
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+        simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, 0, P(out), None))
+        ref = a.float() @ w.float().T + bias
+        assert ((out.float() - ref).abs() <= 2.0 ** -8 * ref.abs() + 2e-3).all(), (ngroup, M, N, K)
+    sim.caco_set_gemm_tile(256)
+
+
+@pytest.mark.parametrize("B,Sq,S,heads,causal,valid", [
+    (3, 32, 32, 12, 1, [32, 12, 1]),       # the text tower: 36 units, causal AND padding
+    (5, 32, 32, 3, 0, [32, 7, 20, 32, 1]),  # 15 units: the last workgroup has an idle wave
+    (2, 64, 64, 2, 1, [64, 33]),           # two key tiles, two query blocks, causal skips the upper-right tile
+    (2, 37, 37, 2, 1, [37, 5]),            # ragged second tile
+    (2, 20, 50, 2, 0, [50, 33]),           # cross-attention lengths
+    (2, 1, 64, 2, 0, [64, 2]),             # a single query row (a cached decode step)
+    (1, 33, 33, 1, 0, [0])])               # every key masked: rows of zeros, no NaN
+def test_attention_small_kernel(sim, monkeypatch, B, Sq, S, heads, causal, valid):
+    """attention_small.hip (one wave per (clip, head, 32-query block), opt-in) against the same checker as the big kernel,
+    and against the big kernel itself."""
+    hd = 64
+    H = heads * hd
+    q = _rand((B, Sq, H), 50, 1.5).bfloat16()
+    kv = _rand((B, S, 2 * H), 51, 1.2).bfloat16()
+    mask = torch.zeros(B, S)
+    for i, n in enumerate(valid):
+        mask[i, :n] = 1
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CACO_ATTN_SMALL", flag)
+        out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16)
+        simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, P(mask), B, S, heads, hd, causal, P(out), None))
+        outs[flag] = out.float()
+    assert torch.isfinite(outs["1"]).all()
+    if valid == [0]:
+        assert (outs["1"] == 0).all()
+        return
+    ref = _attention_ref(q, kv[..., :H], kv[..., H:], mask, heads, hd, bool(causal))
+    live = torch.isfinite(ref).all(-1)                      # rows with at least one visible key
+    assert (outs["1"][live] - ref[live]).abs().max().item() < 0.03
+    assert (outs["1"][~live] == 0).all()
+    assert (outs["1"] - outs["0"]).abs().max().item() < 0.02
+    # no mask pointer
+    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, None, B, S, heads, hd, causal, P(out), None))
+    ref = _attention_ref(q, kv[..., :H], kv[..., H:], None, heads, hd, bool(causal))
+    assert (out.float() - ref).abs().max().item() < 0.03

@@ -570,6 +570,12 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   return CACO_OK;
 }
 
+// CACO_POS_FUSE=1 (read at every call; opt-in until timed on hardware): positional embedding inside the patch-embed GEMM
+bool pos_fuse_enabled() {
+  const char* e = getenv("CACO_POS_FUSE");
+  return e && atoi(e) != 0;
+}
+
 // The model's weights, arenas and per-device kernel state live on ONE device: a call with another device current would
 // dereference foreign memory.  Reject it instead.
 int check_device(const caco_model* m) {
@@ -799,14 +805,31 @@ static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype,
   const size_t o_pool = A.reserve((size_t)batch * c.pool_heads * H * 4);
   const size_t o_pv = A.reserve((size_t)batch * H * 4);
   const size_t o_emb = A.reserve((size_t)batch * c.projection_size * 4);
+  const int nf = c.num_freq_patches, pos_tmax = (seq + nf - 1) / nf + 1;        // time patches a front end can produce for `seq`
+  const size_t o_ptab = A.reserve((size_t)pos_tmax * nf * H * 4);
+  const size_t o_pidx = A.reserve((size_t)M * 4);
   CACO_TRY(A.commit(st));
   float* x = A.at<float>(w.x);
   bf16_t* h = A.at<bf16_t>(w.h);
   const bf16_t* pb = nullptr;
   CACO_STAGE("audio.patch_cast", patches_as_bf16(patches, dtype, M * P, A.at<bf16_t>(o_pb), &pb, st));
-  // AudioEncoder.forward, mae.py:125-148
-  CACO_STAGE("audio.patch_embed", linear_f32(m->enc.input_proj, pb, M, nullptr, x, st));
-  CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, c.num_freq_patches, st));
+  // AudioEncoder.forward, mae.py:125-148: x = input_proj(patches) + sincos(time) + freq_table[freq]
+  GemmArgs gpe{pb, m->enc.input_proj.w, m->enc.input_proj.b, nullptr, x, M, m->enc.input_proj.out, m->enc.input_proj.in, m->enc.input_proj.out};
+  if (pos_fuse_enabled() && gemm_bf16_picks_w8(gpe, EPI_F32)) {
+    // the positional embedding rides in the patch-embed GEMM's epilogue as a gathered residual (norm.hip pos_prepare): no
+    // separate 780 MB read-modify-write pass over x.  Rows whose time index is not a small integer are finished exactly by
+    // add_pos_embed_rest (none with the indices any front end produces: that launch reads M ints and exits).
+    float* ptab = A.at<float>(o_ptab);
+    int* pidx = A.at<int>(o_pidx);
+    CACO_STAGE("audio.pos_embed", pos_prepare(m->enc.freq_table, pos_tmax, nf, H, ptab, tinds, finds, M, pidx, st));
+    gpe.resid = ptab;
+    gpe.resid_idx = pidx;
+    CACO_STAGE("audio.patch_embed", gemm_bf16(gpe, EPI_F32, ACT_NONE, st));
+    CACO_STAGE("audio.pos_embed", add_pos_embed_rest(x, tinds, finds, m->enc.freq_table, pidx, M, H, nf, st));
+  } else {
+    CACO_STAGE("audio.patch_embed", gemm_bf16(gpe, EPI_F32, ACT_NONE, st));
+    CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, nf, st));
+  }
   CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
   // the fp32 hidden states are only written when the caller asks for them (encode_audio does not: 390 MB per batch of 256)
   CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hidden, h, st));

@@ -182,8 +182,8 @@ template <int EPI, int ACT>
 int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   const int cfg = gemm_tile_config();
   const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
-  if (p.fold_mr || p.xb_out || p.stats_part) {      // LayerNorm folding lives in the 8-wave kernel's epilogue only
-    CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16: LayerNorm folding needs N %% 256 == 0 and K %% 64 == 0");
+  if (p.fold_mr || p.xb_out || p.stats_part || p.resid_idx) {      // LayerNorm folding / gathered residual: 8-wave kernel only
+    CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16: LayerNorm folding / a gathered residual need N %% 256 == 0 and K %% 64 == 0");
     return gemm_bf16_w8(p, epi, act, st);
   }
   // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 2256 = 256x128 two workgroups per CU
@@ -203,6 +203,16 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
 }
 
 }  // namespace
+
+// the dispatch rule of launch_epi for callers that only take a w8-specific form when w8 would run anyway
+bool gemm_bf16_picks_w8(const GemmArgs& p, int epi) {
+  const int cfg = gemm_tile_config();
+  if (!gemm_bf16_w8_ok(p, epi) || p.K % BK != 0 || p.N % 128 != 0) return false;
+  if (cfg == 8256) return true;
+  if (cfg != 256) return false;
+  static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
+  return ((p.M + 255) / 256) * (int64_t)(p.N / 128) >= w8_min;
+}
 
 static int g_tile_cfg = -1;
 int gemm_tile_config() {

@@ -22,6 +22,8 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 //   0 generic: bias / residual / LayerNorm-fold consumer / producer outputs all tested at run time
 //   1 bias only        2 bias + residual (EPI_F32)
 //   3 bias + LayerNorm-fold consumer (EPI_BF16)        4 bias + residual + fold producer (EPI_F32: bf16 copy + row sums)
+//   5 bias + GATHERED residual (EPI_F32): row m adds resid[resid_idx[m], :] of a small table (row stride ldc); an index
+//     < 0 wraps past the descriptor's range and reads as 0.  The patch-embed GEMM's positional embedding (api.hip).
 // Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
 // fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
 // (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
@@ -123,13 +125,22 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs; the residual of slab s+1 is fetched while slab s is processed
     const int rowb = p.ldc * 4;
     const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
-    const bool has_resid = MODE ? (MODE == 2 || MODE == 4) : p.resid != nullptr;
+    const bool has_resid = MODE ? (MODE == 2 || MODE == 4 || MODE == 5) : p.resid != nullptr;
     const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
     const bool produce_st = MODE ? MODE == 4 : p.stats_part != nullptr;
     const __amdgpu_buffer_rsrc_t out_r =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t res_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, has_resid ? bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_r =
+        MODE == 5 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.resid) + nw, 0, 0x7fffffff, 0x00020000)
+                  : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_resid ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw,
+                                                      0, has_resid ? bytes : 0, 0x00020000);
+    int gidx[4][4];                     // MODE 5: table row of output row i*32 + tt*8 + rrow (rows past M: the last row's; never stored)
+    if constexpr (MODE == 5) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) gidx[i][tt] = p.resid_idx[min(mw + i * 32 + tt * 8 + rrow, p.M - 1)];
+    }
     const int voff = rrow * rowb + c8 * 16;
     const __amdgpu_buffer_rsrc_t xb_r = __builtin_amdgcn_make_buffer_rsrc(
         produce_xb ? p.xb_out + mw * p.ldc + nw : reinterpret_cast<bf16_t*>(p.out), 0, produce_xb ? bytes >> 1 : 0, 0x00020000);
@@ -139,7 +150,10 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
     auto fetch = [&](int s, u32x4 (&dst)[4]) {
       const int i = s >> 1, j = s & 1;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
+      for (int tt = 0; tt < 4; ++tt) {
+        if constexpr (MODE == 5) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, gidx[i][tt] * rowb + c8 * 16, j * 128, 0);   // table rows are re-used: default cache policy
+        else dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
+      }
     };
     if (has_resid) {
 #pragma unroll

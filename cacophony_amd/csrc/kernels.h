@@ -27,6 +27,10 @@ struct GemmArgs {
   // producer, EPI_F32: besides out (fp32) also a bf16 copy of the same rows and per-row partial statistics
   bf16_t* xb_out;         // [M, ldc] bf16 copy of out, or null
   float* stats_part;      // [M, N/64] (sum, sum of squares) pairs over each wave's 64 columns, or null
+  // gathered residual (8-wave kernel, EPI_F32): row m adds resid[resid_idx[m], :] - `resid` is then a small TABLE of rows
+  // (row stride ldc) instead of an [M, ldc] matrix; an index < 0 adds nothing.  The patch-embed GEMM adds the positional
+  // embedding this way (api.hip).  null = `resid` is indexed by the output row as usual.
+  const int* resid_idx;
 };
 
 // Per-device launch preparation shared by every kernel that needs more than 64 KiB of dynamic LDS or sizes its grid by the
@@ -44,6 +48,7 @@ int prepare_launch(const void* kern, int dyn_lds_bytes, int* num_cu);      // ap
 int gemm_tile_config();
 int set_gemm_tile_config(int tile);
 int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);
+bool gemm_bf16_picks_w8(const GemmArgs& p, int epi);                      // gemm.hip: would gemm_bf16 send this shape to w8?
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w8_ok(const GemmArgs& p, int epi);                         // gemm_w8.hip: persistent 256x256, the default
 int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st);
@@ -60,6 +65,12 @@ int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word,
 // x[m, :] (+)= sincos(time[m]) + freq_table[freq[m], :] (+ base[:] when base != null, replacing x)
 int add_pos_embed(float* x, const float* base, const float* time_inds, const float* freq_inds, const float* freq_table,
                   int64_t rows, int dim, int num_freq, hipStream_t st);
+// positional embedding as a gathered residual of the patch-embed GEMM (norm.hip): table [tmax * num_freq, dim] and per-row
+// table indices (-1 = not an integer position: that row is finished by add_pos_embed_rest afterwards)
+int pos_prepare(const float* freq_table, int tmax, int num_freq, int dim, float* table, const float* time_inds,
+                const float* freq_inds, int64_t rows, int* idx, hipStream_t st);
+int add_pos_embed_rest(float* x, const float* time_inds, const float* freq_inds, const float* freq_table, const int* idx,
+                       int64_t rows, int dim, int num_freq, hipStream_t st);
 // LayerNorm folding helpers: per-row (mean, rstd) from the GEMM epilogue's partial sums / from fp32 rows (+ bf16 copy)
 int ln_stats_finalize(const float* part, int nslot, int64_t rows, int dim, float eps, float* mr, hipStream_t st);
 int row_stats_bf16(const float* x, int64_t rows, int dim, float eps, bf16_t* xb, float* mr, hipStream_t st);

@@ -167,6 +167,26 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restri
 
 // x[m, n] = (base ? base[n] : x[m, n]) + sincos(time[m])[n] + freq_table[freq[m]][n]
 // sincos: n < dim/2 -> sin(t * w_n), else cos(t * w_{n - dim/2}); w_i = exp(2 i * (-ln 1e4) / dim)  (mae.py:102-109)
+__device__ __forceinline__ void pos_embed_row(float* __restrict__ xrow, const float* __restrict__ base, float t, int f,
+                                              const float* __restrict__ freq_table, int dim, int lane) {
+  const int half = dim >> 1;
+  const float kf = -9.210340371976184f / (float)dim;  // -ln(10000) / dim
+  for (int ch = lane; ch < (dim >> 2); ch += 64) {
+    f32x4 v = base ? *reinterpret_cast<const f32x4*>(base + ch * 4) : *reinterpret_cast<const f32x4*>(xrow + ch * 4);
+    const f32x4 fe = *reinterpret_cast<const f32x4*>(freq_table + (int64_t)f * dim + ch * 4);
+    f32x4 te;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = ch * 4 + r;
+      const int i = n < half ? n : n - half;
+      const float ang = t * expf((2.0f * (float)i) * kf);
+      te[r] = n < half ? sinf(ang) : cosf(ang);
+    }
+    v = (v + te) + fe;   // x + time_pos_emb, then + freq_pos_emb (mae.py:141-142)
+    *reinterpret_cast<f32x4*>(xrow + ch * 4) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void add_pos_embed_kernel(float* __restrict__ x, const float* __restrict__ base,
                                                             const float* __restrict__ time_inds,
                                                             const float* __restrict__ freq_inds,
@@ -178,23 +198,50 @@ __global__ __launch_bounds__(256) void add_pos_embed_kernel(float* __restrict__ 
   const float t = time_inds[row];
   int f = (int)freq_inds[row];     // .long() truncation, mae.py:139
   f = f < 0 ? 0 : (f >= num_freq ? num_freq - 1 : f);
-  const int half = dim >> 1;
-  const float kf = -9.210340371976184f / (float)dim;  // -ln(10000) / dim
-  for (int ch = lane; ch < (dim >> 2); ch += 64) {
-    f32x4 v = base ? *reinterpret_cast<const f32x4*>(base + ch * 4)
-                   : *reinterpret_cast<const f32x4*>(x + row * dim + ch * 4);
-    const f32x4 fe = *reinterpret_cast<const f32x4*>(freq_table + (int64_t)f * dim + ch * 4);
-    f32x4 te;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = ch * 4 + r;
-      const int i = n < half ? n : n - half;
-      const float ang = t * expf((2.0f * (float)i) * kf);
-      te[r] = n < half ? sinf(ang) : cosf(ang);
-    }
-    v = (v + te) + fe;   // x + time_pos_emb, then + freq_pos_emb (mae.py:141-142)
-    *reinterpret_cast<f32x4*>(x + row * dim + ch * 4) = v;
+  pos_embed_row(x + row * dim, base, t, f, freq_table, dim, lane);
+}
+
+// ---- positional embedding through the patch-embed GEMM's epilogue (api.hip, GemmArgs::resid_idx) ------------------------
+// The indices a front end produces are small integers (time patch 0 .. S/8, frequency patch 0 .. 7: eval_caco_torch.py
+// :139-144), so the [M, dim] embedding is a gather from a table of tmax * num_freq distinct rows:
+//   table[t * num_freq + f, :] = (0 + sincos(t)) + freq_table[f]        (the same expressions as pos_embed_row)
+//   idx[m] = t * num_freq + f   when time_inds[m] is an integer in [0, tmax);  -1 otherwise
+// Rows with idx < 0 (a caller is free to pass any float: get_sin_cos_pos_embed takes float positions, mae.py:102-109) get
+// nothing from the GEMM and the exact per-row form afterwards (add_pos_embed_rest_kernel), so the result does not depend on
+// the indices being integers - only the speed does.  One launch: blocks [0, table_blocks) build the table, the rest the indices.
+__global__ __launch_bounds__(256) void pos_prepare_kernel(const float* __restrict__ freq_table, int tmax, int num_freq, int dim,
+                                                          float* __restrict__ table, int table_blocks,
+                                                          const float* __restrict__ time_inds, const float* __restrict__ freq_inds,
+                                                          int64_t rows, int* __restrict__ idx) {
+  if ((int)blockIdx.x < table_blocks) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= tmax * num_freq) return;
+    float* trow = table + (int64_t)r * dim;
+    for (int ch = lane; ch < (dim >> 2); ch += 64) *reinterpret_cast<f32x4*>(trow + ch * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    pos_embed_row(trow, nullptr, (float)(r / num_freq), r % num_freq, freq_table, dim, lane);   // each lane re-reads its own zeros
+    return;
   }
+  const int64_t m = (int64_t)(blockIdx.x - table_blocks) * 256 + threadIdx.x;
+  if (m >= rows) return;
+  const float t = time_inds[m];
+  int f = (int)freq_inds[m];
+  f = f < 0 ? 0 : (f >= num_freq ? num_freq - 1 : f);
+  const int ti = (int)t;
+  idx[m] = (t >= 0.f && t < (float)tmax && (float)ti == t) ? ti * num_freq + f : -1;
+}
+
+__global__ __launch_bounds__(256) void add_pos_embed_rest_kernel(float* __restrict__ x, const float* __restrict__ time_inds,
+                                                                 const float* __restrict__ freq_inds,
+                                                                 const float* __restrict__ freq_table, const int* __restrict__ idx,
+                                                                 int64_t rows, int dim, int num_freq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows || idx[row] >= 0) return;            // the GEMM epilogue already added this row's embedding
+  const float t = time_inds[row];
+  int f = (int)freq_inds[row];
+  f = f < 0 ? 0 : (f >= num_freq ? num_freq - 1 : f);
+  pos_embed_row(x + row * dim, nullptr, t, f, freq_table, dim, lane);
 }
 
 __global__ void mask_i64_to_f32_kernel(const int64_t* __restrict__ in, float* __restrict__ out, int64_t n) {
@@ -277,6 +324,23 @@ int add_pos_embed(float* x, const float* base, const float* time_inds, const flo
   hipLaunchKernelGGL(add_pos_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, base, time_inds,
                      freq_inds, freq_table, rows, dim, num_freq);
   return check_hip(hipGetLastError(), "add_pos_embed launch");
+}
+
+int pos_prepare(const float* freq_table, int tmax, int num_freq, int dim, float* table, const float* time_inds,
+                const float* freq_inds, int64_t rows, int* idx, hipStream_t st) {
+  CACO_REQUIRE(dim % 8 == 0 && tmax > 0 && num_freq > 0, "pos_prepare: bad table shape");
+  const int table_blocks = (tmax * num_freq + 3) / 4;
+  const int64_t idx_blocks = (rows + 255) / 256;
+  hipLaunchKernelGGL(pos_prepare_kernel, dim3((unsigned)(table_blocks + idx_blocks)), dim3(256), 0, st, freq_table, tmax, num_freq,
+                     dim, table, table_blocks, time_inds, freq_inds, rows, idx);
+  return check_hip(hipGetLastError(), "pos_prepare launch");
+}
+
+int add_pos_embed_rest(float* x, const float* time_inds, const float* freq_inds, const float* freq_table, const int* idx,
+                       int64_t rows, int dim, int num_freq, hipStream_t st) {
+  hipLaunchKernelGGL(add_pos_embed_rest_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, time_inds, freq_inds,
+                     freq_table, idx, rows, dim, num_freq);
+  return check_hip(hipGetLastError(), "add_pos_embed_rest launch");
 }
 
 int mask_i64_to_f32(const int64_t* in, float* out, int64_t n, hipStream_t st) {

@@ -494,3 +494,37 @@ def test_unindexed_device_and_host_inputs_to_encode_pairs(tiny_state):
     assert torch.equal(ea, ra) and torch.equal(et, rt)
     with pytest.raises(ValueError):
         m.encode_pairs(torch.from_numpy(wav), ids, tmask, lengths=[32000])
+
+
+def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
+    """CACO_POS_FUSE=1: the positional embedding as a gathered residual of the patch-embed GEMM instead of a separate pass
+    (same case as tests/test_wavesim.py, at a batch the persistent kernel is the default for).  Same hidden states up to fp32
+    re-association; rows whose time index is not a small integer take the exact per-row kernel and are bit-identical."""
+    _, ab = _audio_batch(40, start=7)                    # M = 20 000: w8 is what gemm_bf16 picks
+    tin = ab["audio_time_inds"].clone()
+    tin[1, 5] = 2.5
+    tin[2, 7] = 4000.0
+    tin[0, 9] = -1.0
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CACO_POS_FUSE", flag)
+        emb, hid = full_model.get_audio_embedding(ab["audio_patches"], tin, ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
+        outs[flag] = (emb.cpu().numpy(), hid.cpu().numpy())
+    assert np.isfinite(outs["1"][1]).all()
+    assert rel_l2(outs["1"][1][:, :496], outs["0"][1][:, :496]) < 1e-3
+    assert cosine_rows(outs["1"][0], outs["0"][0]).min() > 0.99999
+
+
+def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch):
+    """Every round-3 opt-in at once (fused positional embedding, short-sequence attention kernel) against the reference's
+    own outputs, full and tiny configuration."""
+    monkeypatch.setenv("CACO_POS_FUSE", "1")
+    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    _check_against_golden(full_model, load_golden("caco_full.npz"), 4, 50265)
+    a, t, cc = C.tiny_configs(2)
+    tm = CACO(a, t, cc, device=DEV).load_state_dict(tiny_state)
+    full_model._lib.caco_set_gemm_tile(8256)
+    try:
+        _check_against_golden(tm, load_golden("caco_tiny.npz"), 2, 1024)
+    finally:
+        full_model._lib.caco_set_gemm_tile(256)

@@ -409,3 +409,48 @@ def test_attention_small_kernel(sim, monkeypatch, B, Sq, S, heads, causal, valid
     simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, None, B, S, heads, hd, causal, P(out), None))
     ref = _attention_ref(q, kv[..., :H], kv[..., H:], None, heads, hd, bool(causal))
     assert (out.float() - ref).abs().max().item() < 0.03
+
+
+def test_pos_embed_in_the_patch_embed_epilogue(sim, tiny_state, monkeypatch):
+    """CACO_POS_FUSE=1: the positional embedding as a gathered residual of the patch-embed GEMM (w8 MODE 5) instead of a
+    separate pass.  Same hidden states as the separate kernel (fp32 re-association only), also for positions that are not
+    small integers (those rows are finished by the exact per-row kernel) and for a ragged last M tile."""
+    from dataclasses import replace
+    a, t, cc = C.tiny_configs(2)
+    a1 = replace(a, num_layers=0)                      # patch embed + positional embedding + final LayerNorm only
+    m = simlib.SimModel(a1, None, cc).load_state_dict({k: v for k, v in tiny_state.items() if k.startswith("audio_") and ".layers." not in k})
+    wav = synth.make_waveforms(3, n_samples=41000, start=3)
+    ab = _mel_patches(sim, wav, 130)                   # M = 390: one full and one ragged 256-row tile
+    tin = ab["audio_time_inds"].clone()
+    tin[1, 5] = 2.5                                     # not an integer
+    tin[2, 7] = 4000.0                                  # integer, far outside the table
+    tin[0, 9] = -1.0
+    sim.caco_set_gemm_tile(8256)
+    try:
+        outs = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("CACO_POS_FUSE", flag)
+            _, hid = m.audio_forward(ab["audio_patches"], tin, ab["audio_freq_inds"], ab["audio_mask"])
+            outs[flag] = hid.numpy()
+    finally:
+        sim.caco_set_gemm_tile(256)
+    assert np.isfinite(outs["1"]).all()
+    assert np.abs(outs["1"] - outs["0"]).max() < 2e-5
+    assert (outs["1"] != outs["0"]).any()               # (x + te) + fe vs x + (te + fe): the other path did run
+    for (b, p) in ((1, 5), (2, 7), (0, 9)):             # the exact path's rows are bit-identical
+        np.testing.assert_array_equal(outs["1"][b, p], outs["0"][b, p])
+    o = O.CacoOracle(tiny_state, a1, t, cc, backend="torch")
+    _, ref = o.get_audio_embedding(ab["audio_patches"].numpy(), tin.numpy(), ab["audio_freq_inds"].numpy(), ab["audio_mask"].numpy())
+    assert rel_l2(outs["1"], ref) < 5e-3
+
+
+def test_tiny_config_golden_with_round3_switches(sim, tiny_state, monkeypatch):
+    """The 2-layer towers against the reference golden with every round-3 opt-in on at once (fused positional embedding,
+    short-sequence attention kernel), on the persistent GEMM."""
+    monkeypatch.setenv("CACO_POS_FUSE", "1")
+    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    sim.caco_set_gemm_tile(8256)
+    try:
+        test_tiny_config_matches_reference_golden(sim, tiny_state, 0)
+    finally:
+        sim.caco_set_gemm_tile(256)

@@ -2,7 +2,8 @@
 # ISA identity check of the shipped kernels against a git ref (default HEAD): compiles every csrc/*.hip of both trees
 # for gfx950 (device only, -S) with the library's flags and diffs the assembly, ignoring the per-build __hip_cuid symbol.
 #   tools/isa_diff.sh [ref] [file.hip ...]
-# Exit status 0 = every translation unit's ISA is identical.  Used while the GPU pool is closed: the default build must
+# A translation unit that differs is compared kernel by kernel (tools/isa_funcs.py: identical / CHANGED / NEW).
+# Exit status 0 = no existing kernel's instruction stream changed (new kernels are allowed).  Used while the GPU pool is closed: the default build must
 # stay the build that was last verified on hardware; new kernels go in behind switches.
 set -u
 REF=${1:-HEAD}; shift || true
@@ -23,7 +24,7 @@ for f in "${FILES[@]}"; do
   f=${f%.hip}
   if [ ! -s "$OLD/$f.s" ]; then echo "$f: not in $REF (new file)"; continue; fi
   if diff -q <(grep -v "__hip_cuid" "$OLD/$f.s") <(grep -v "__hip_cuid" "$NEW/$f.s") >/dev/null; then echo "$f: identical"
-  else echo "$f: DIFFERS ($(diff <(grep -v "__hip_cuid" "$OLD/$f.s") <(grep -v "__hip_cuid" "$NEW/$f.s") | grep -c '^[<>]') lines)"; rc=1; fi
+  else echo "$f: differs - per kernel:"; python3 "$REPO/tools/isa_funcs.py" "$OLD/$f.s" "$NEW/$f.s" | sed 's/^/    /'; [ ${PIPESTATUS[0]} -ne 0 ] && rc=1; fi
 done
 rm -rf "$OLD" "$NEW"
 exit $rc

@@ -9,6 +9,7 @@ The model is pinned the other way round as well: the kernels it executes here pa
 1 and 2, so a wrong instruction model would show up as a failure of a known-good kernel.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -454,3 +455,13 @@ def test_tiny_config_golden_with_round3_switches(sim, tiny_state, monkeypatch):
         test_tiny_config_matches_reference_golden(sim, tiny_state, 0)
     finally:
         sim.caco_set_gemm_tile(256)
+
+
+@pytest.mark.skipif(os.environ.get("CACO_SIM_ASAN", "0") in ("", "0"), reason="set CACO_SIM_ASAN=1: builds the ASan variant of the simulator (~2 min)")
+def test_kernels_and_c_abi_are_asan_clean():
+    """tools/wavesim/asan_check.py: every kernel and the C-ABI layer under AddressSanitizer with exactly-sized buffers and
+    ragged shapes (the GPU pool has no device sanitizer; result recorded in profiles/r3_cpu/asan.txt)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(simlib.REPO, "tools", "wavesim", "asan_check.py")], capture_output=True, text=True)
+    assert r.returncode == 0 and "ASAN CLEAN" in r.stdout, r.stdout[-4000:]

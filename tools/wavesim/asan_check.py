@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""AddressSanitizer run of the kernels and of the C-ABI layer (csrc/api.hip) on the wavesim build: every "device" buffer
+is a host allocation, so a kernel that reads or writes past a buffer - global memory or LDS statics - is reported by ASan
+with the source line.  (GPU AddressSanitizer is not available on this pool; this is the CPU-side substitute.)
+
+    python tools/wavesim/asan_check.py            # builds tools/wavesim/libcaco_sim_asan.so, runs the driver below under it
+
+The driver avoids torch (an uninstrumented interpreter plus torch under ASan is slow): numpy + ctypes only.  Shapes are
+chosen ragged on purpose: M, S, T not multiples of any tile, per-clip lengths, the last clip's mask row at the very end of
+its buffer.  Exit status 0 and "ASAN CLEAN" on the last line = no report."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+DRIVER = r'''
+import ctypes as C, math, os, sys
+import numpy as np
+sys.path.insert(0, REPO)
+from cacophony_amd import _lib, config as Cfg, synth
+lib = C.CDLL(LIB)
+for name, (res, args) in _lib._SIGNATURES.items():
+    fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+P = lambda a: C.c_void_p(0 if a is None else a.ctypes.data)
+def chk(rc, what=""):
+    assert rc == 0, (what, lib.caco_last_error())
+def bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+rng = np.random.default_rng(0)
+# exact-size allocations: every array below is exactly as large as the call says
+for tile in (128, 2256, 8256):
+    lib.caco_set_gemm_tile(tile)
+    for (M, N, K, act) in ((301, 256, 128, 1), (77, 768, 64, 0), (515, 512, 192, 2)):
+        a, w, b = bf16(rng.standard_normal((M, K))), bf16(rng.standard_normal((N, K)) / math.sqrt(K)), rng.standard_normal(N).astype(np.float32)
+        out = np.zeros((M, N), np.uint16)
+        chk(lib.caco_op_gemm_bf16(P(a), P(w), P(b), M, N, K, act, P(out), None), "gemm")
+        x = rng.standard_normal((M, N)).astype(np.float32)
+        chk(lib.caco_op_gemm_bf16_f32out(P(a), P(w), P(b), P(x), M, N, K, P(x), None), "gemm f32")
+lib.caco_set_gemm_tile(256)
+for env in ("0", "1"):
+    os.environ["CACO_ATTN_SMALL"] = env
+    for (B, S, heads, hd, causal) in ((2, 197, 2, 96, 0), (3, 31, 3, 64, 1), (1, 130, 1, 96, 1), (2, 61, 2, 64, 0)):
+        H = heads * hd
+        qkv = bf16(rng.standard_normal((B, S, 3 * H)))
+        mask = np.ones((B, S), np.float32); mask[-1, S // 2:] = 0
+        out = np.zeros((B, S, H), np.uint16)
+        chk(lib.caco_op_attention(P(qkv), 3 * H, H, 2 * H, P(mask), B, S, heads, hd, causal, P(out), None), "attention")
+x = rng.standard_normal((203, 768)).astype(np.float32); g = np.ones(768, np.float32); o32 = np.zeros_like(x); o16 = np.zeros((203, 768), np.uint16)
+chk(lib.caco_op_layernorm(P(x), P(g), P(g), 203, 768, 1e-5, P(o32), P(o16), None), "layernorm")
+# front end: ragged lengths, odd sample count (unaligned path)
+for n, maxp, lens in ((12345, 64, None), (48001, 150, [48001, 20000, 7000]), (700, 16, None)):
+    Bm = 3 if lens else 1
+    wav = (rng.standard_normal((Bm, n)) * 0.1).astype(np.float32)
+    ln = None if lens is None else np.asarray(lens, np.int64)
+    for dt, npdt in ((0, np.float32), (1, np.uint16)):
+        patches = np.zeros((Bm, maxp, 256), npdt); ti = np.zeros((Bm, maxp), np.float32); fi = ti.copy(); mk = ti.copy()
+        chk(lib.caco_mel_patches_lens(P(wav), P(ln), Bm, n, maxp, 0.2, 0.9, P(patches), dt, P(ti), P(fi), P(mk), None), "mel")
+# whole towers, tiny configuration, every round-3 switch on and off
+a, t, cc = Cfg.tiny_configs(1)
+state = synth.make_caco_state(a, t, cc)
+cfg = _lib.CacoConfigC(); lib.caco_default_config(C.byref(cfg))
+cfg.audio_layers, cfg.text_layers, cfg.text_vocab = 1, 1, t.vocab_size
+h = C.c_void_p(); chk(lib.caco_create(C.byref(cfg), C.byref(h)), "create")
+for k, v in state.items():
+    arr = np.ascontiguousarray(v, np.float32); shp = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+    chk(lib.caco_load_tensor(h, k.encode(), P(arr), shp, arr.ndim), k)
+chk(lib.caco_finalize_weights(h), "finalize")
+for flags in (("0", "0"), ("1", "1")):
+    os.environ["CACO_POS_FUSE"], os.environ["CACO_ATTN_SMALL"] = flags
+    lib.caco_set_gemm_tile(8256 if flags[0] == "1" else 256)
+    wav = (rng.standard_normal((3, 33000)) * 0.1).astype(np.float32)
+    emb = np.zeros((3, 768), np.float32)
+    chk(lib.caco_encode_audio_ex(h, P(wav), P(np.asarray([33000, 9000, 20000], np.int64)), 3, 33000, 103, P(emb), 0, None), "encode_audio")
+    ids, mask = synth.make_captions(5, 29, t.vocab_size)
+    et = np.zeros((5, 768), np.float32)
+    chk(lib.caco_encode_text(h, P(ids), P(mask), 5, 29, P(et), 0, None), "encode_text")
+    sim = np.zeros((3, 5), np.float32)
+    chk(lib.caco_similarity(P(emb), 3, P(et), 5, 768, 1.0, P(sim), 5, None), "similarity")
+    idx = np.zeros((3, 4), np.int32); val = np.zeros((3, 4), np.float32)
+    chk(lib.caco_topk(P(sim), 3, 5, 5, 1, 4, P(idx), P(val), None), "topk")
+    assert np.isfinite(sim).all()
+lib.caco_destroy(h)
+print("DRIVER DONE")
+'''
+
+
+def main():
+    sys.path.insert(0, HERE)
+    import build_sim
+    lib = build_sim.build(asan=True, lib=os.path.join(HERE, "libcaco_sim_asan.so"), verbose=False)
+    rt = subprocess.run([build_sim.CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        rt = subprocess.run([build_sim.CXX, "-print-file-name=libclang_rt.asan.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:detect_stack_use_after_return=0",
+               WAVESIM_THREADS="4", OMP_NUM_THREADS="1")
+    code = f"REPO = {REPO!r}\nLIB = {lib!r}\n" + DRIVER
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    sys.stdout.write(r.stdout[-3000:])
+    err = r.stderr
+    bad = "AddressSanitizer" in err or r.returncode != 0 or "DRIVER DONE" not in r.stdout
+    if bad:
+        sys.stdout.write(err[-6000:])
+        print("ASAN REPORT OR FAILURE (exit %d)" % r.returncode)
+        return 1
+    print("ASAN CLEAN")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

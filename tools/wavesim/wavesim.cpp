@@ -35,6 +35,22 @@ wavesim_switch:
 .size wavesim_switch,.-wavesim_switch
 )");
 
+// AddressSanitizer build (build_sim.py --asan): stack switches are announced so that ASan follows the fibers' stacks
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define WAVESIM_ASAN 1
+#endif
+#endif
+#ifdef WAVESIM_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#define WAVESIM_ASAN_START(save, bottom, size) __sanitizer_start_switch_fiber(save, bottom, size)
+#define WAVESIM_ASAN_FINISH(save, bottom_old, size_old) __sanitizer_finish_switch_fiber(save, bottom_old, size_old)
+#else
+#define WAVESIM_ASAN_START(save, bottom, size) ((void)0)
+#define WAVESIM_ASAN_FINISH(save, bottom_old, size_old) ((void)0)
+#endif
+
 namespace wavesim {
 
 WAVESIM_TLS Lane* cur = nullptr;
@@ -53,6 +69,8 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
   Wave* waves = nullptr;
   char* lds = nullptr;
   void* main_sp = nullptr;
+  const void* main_stack_bottom = nullptr;      // ASan: the scheduler's own stack, learnt at the first switch into a lane
+  size_t main_stack_size = 0;
   const std::function<void()>* body = nullptr;
   ~Worker() {
     if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
@@ -75,17 +93,24 @@ WAVESIM_TLS Worker* tl_w = &g_workers[0];
 
 void lane_entry() {
   Worker& W = *tl_w;
+  WAVESIM_ASAN_FINISH(nullptr, &W.main_stack_bottom, &W.main_stack_size);
   (*W.body)();
   Lane* L = cur;
   L->state = 3;
   while (L->vm_count) vm_retire_one(L);     // outstanding DMA still lands (nobody can observe it any more)
+  WAVESIM_ASAN_START(nullptr, W.main_stack_bottom, W.main_stack_size);      // null: this fiber never comes back
   wavesim_switch(&L->sp, W.main_sp);
   fail("resumed a finished lane");
 }
 
 void yield_to_scheduler() {
   Lane* L = cur;
-  wavesim_switch(&L->sp, tl_w->main_sp);
+  Worker& W = *tl_w;
+  void* fake = nullptr;
+  (void)fake;
+  WAVESIM_ASAN_START(&fake, W.main_stack_bottom, W.main_stack_size);
+  wavesim_switch(&L->sp, W.main_sp);
+  WAVESIM_ASAN_FINISH(fake, nullptr, nullptr);
 }
 
 void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& body) {
@@ -135,7 +160,11 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
           Lane* L = wv.lanes[l];
           while (L->state == 0) {
             cur = L;
+            void* fake = nullptr;
+            (void)fake;
+            WAVESIM_ASAN_START(&fake, L->stack, STACK_BYTES);
             wavesim_switch(&W.main_sp, L->sp);
+            WAVESIM_ASAN_FINISH(fake, nullptr, nullptr);
             progress = true;
           }
         }

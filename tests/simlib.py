@@ -92,9 +92,10 @@ class SimModel:
         check(self.lib.caco_create(C.byref(cfg), C.byref(self.h)), "caco_create")
 
     def __del__(self):
-        if getattr(self, "h", None) is not None and self.h.value:
-            self.lib.caco_destroy(self.h)
-            self.h = C.c_void_p()
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            self.lib.caco_destroy(h)
+            self.h = None
 
     def load_state_dict(self, state: Mapping[str, object]) -> "SimModel":
         for name, value in state.items():

@@ -465,3 +465,84 @@ def test_kernels_and_c_abi_are_asan_clean():
     import sys
     r = subprocess.run([sys.executable, os.path.join(simlib.REPO, "tools", "wavesim", "asan_check.py")], capture_output=True, text=True)
     assert r.returncode == 0 and "ASAN CLEAN" in r.stdout, r.stdout[-4000:]
+
+
+# ------------------------------------------------------------------------------------------------ the other entry points
+def test_audiomae_matches_reference_golden(sim):
+    """AudioMAE.forward (mae.py:217-247): 2-layer encoder on 100 visible patches + 2-layer decoder on all 496, against the
+    reference's own output rows (tests/golden/mae_tiny.npz)."""
+    from dataclasses import replace
+    g = load_golden("mae_tiny.npz")
+    enc = replace(C.default_audio_config(), num_layers=2)
+    m = simlib.SimModel(enc, None, C.default_caco_config(), mae_decoder_layers=2).load_state_dict(synth.make_audiomae_state(enc, enc))
+    ab = _mel_patches(sim, synth.make_waveforms(2), 500)
+    sp = synth.make_mae_split(2, 496, 100, 8)
+    np.testing.assert_array_equal(sp["visible"], g["visible"])
+    vis = torch.from_numpy(sp["visible"])
+    x = torch.stack([ab["audio_patches"][i][vis[i]] for i in range(2)]).contiguous()
+    f = lambda a: torch.as_tensor(a).float().contiguous()
+    out = torch.empty(2, 496, 256)
+    args = [f(torch.ones(2, 100)), f(sp["time_inds"]), f(sp["freq_inds"]), f(sp["restore_time_inds"]), f(sp["restore_freq_inds"]),
+            f(torch.ones(2, 396))]                      # kept alive across the call: P() only takes the address
+    simlib.check(sim.caco_mae_forward(m.h, P(x), 0, *[P(t) for t in args], 2, 100, 396, P(out), None), "mae_forward")
+    assert rel_l2(out.numpy()[:, g["rows"]], g["out_rows"]) < 1e-2
+
+
+def _decoder_model(sim):
+    from dataclasses import replace
+    a, t, cc = C.tiny_configs(2)
+    d = replace(t, num_hidden_layers=2)
+    state = synth.make_caco_state(a, t, cc, seed=0, decoder_cfg=d)
+    return simlib.SimModel(a, t, cc, caption_decoder_layers=2).load_state_dict(state), t
+
+
+def test_caption_decoder_ragged_masks_and_cached_steps(sim):
+    """RobertaDecoder.forward (roberta.py:337-373) on seeded states with ragged masks on both sides against the reference's
+    logits (decoder_tiny.npz `rand_logits`), the masked-audio-token invariance, and caco_decode_step (key / value caches)
+    against the full-prefix form position by position."""
+    import ctypes
+    g = load_golden("decoder_tiny.npz")
+    m, t = _decoder_model(sim)
+    H, V = t.hidden_size, t.vocab_size
+    rng = np.random.RandomState(5)
+    th = torch.from_numpy(rng.randn(2, 20, H).astype(np.float32))
+    ah = torch.from_numpy(rng.randn(2, 70, H).astype(np.float32))
+    tm = torch.ones(2, 20, dtype=torch.int64); tm[1, 13:] = 0
+    am = torch.ones(2, 70); am[0, 50:] = 0
+
+    def dec(th_, tm_, ah_, am_):
+        lg = torch.empty(th_.shape[0], th_.shape[1], V)
+        simlib.check(sim.caco_decoder_forward(m.h, P(th_), P(tm_), P(ah_), P(am_), th_.shape[0], th_.shape[1], ah_.shape[1], P(lg), None), "decoder")
+        return lg.numpy()
+    lg = dec(th, tm, ah, am)
+    keep = tm.numpy().astype(bool)
+    assert rel_l2(lg[keep], g["rand_logits"][keep]) < 1e-2
+    assert cosine_rows(lg[keep], g["rand_logits"][keep]).min() > 0.999
+    ah2 = ah.clone(); ah2[0, 50:] = 100.0
+    np.testing.assert_array_equal(dec(th, tm, ah2, am)[0], lg[0])
+    # cached steps == text tower + decoder on the growing prefix
+    ids = torch.from_numpy(g["ids"][:, :6]).contiguous()
+    _, thid = m.text_forward(ids, torch.ones_like(ids))
+    full = dec(thid.contiguous(), torch.ones_like(ids), ah, am)
+    st = ctypes.c_void_p()
+    simlib.check(sim.caco_decode_begin(m.h, P(ah), P(am), 2, 70, 8, ctypes.byref(st), None), "decode_begin")
+    try:
+        for p in range(6):
+            tok = ids[:, p].contiguous()
+            lgp = torch.empty(2, V)
+            simlib.check(sim.caco_decode_step(st, P(tok), P(lgp), None), "decode_step")
+            assert rel_l2(lgp.numpy(), full[:, p]) < 3e-3, p
+    finally:
+        sim.caco_decode_end(st)
+
+
+def test_token_group_mean_and_strided_similarity(sim):
+    x = _rand((2, 37, 768), 60)
+    out = torch.empty(2, 4, 768)
+    simlib.check(sim.caco_token_group_mean(P(x), 2, 37, 768, 8, P(out), None))
+    np.testing.assert_allclose(out.numpy(), x[:, :32].reshape(2, 4, 8, 768).mean(2).numpy(), atol=1e-6)
+    bank = torch.nn.functional.normalize(_rand((9, 2, 768), 61), dim=-1).contiguous()      # packed [B, 2, P] exchange buffer
+    sim_m = torch.full((9, 12), float("nan"))
+    simlib.check(sim.caco_similarity_ld(P(bank[:, 0]), 9, 2 * 768, P(bank[:, 1]), 9, 2 * 768, 768, 2.0, P(sim_m), 12, None))
+    ref = 2.0 * bank[:, 0].double() @ bank[:, 1].double().T
+    assert (sim_m[:, :9].double() - ref).abs().max().item() < 1e-5 and torch.isnan(sim_m[:, 9:]).all()

@@ -1,0 +1,43 @@
+#!/bin/bash
+# The first GPU call once the pool reopens (round 3 wrote everything below without one):
+#   gpurun --timeout 2400 -- 'bash tools/r3_gpu_session.sh'
+# 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
+# 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | both | CACO_W_NGROUP=0
+# 3. rocprofv3 kernel stats of the default build and of the build with both switches on
+# Every part is wrapped in its own timeout so that a hang cannot eat the call.
+set -u
+OUT=gpurun_out/r3_v0
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
+(timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25) > "$OUT/pytest_gpu.txt"
+tail -3 "$OUT/pytest_gpu.txt"
+(timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > "$OUT/smoke.txt"
+cat "$OUT/smoke.txt"
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+head -c 600 "$OUT/bench.json"; echo
+ab() {   # name, env assignments...
+  local name=$1; shift
+  env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); s=d['stages']
+    keys=('audio.gemm_fc1','audio.gemm_qkv','audio.gemm_fc2','audio.gemm_out','audio.attention','audio.ln','audio.pos_embed','audio.patch_embed','text.attention')
+    print('$name', d['ms_per_step'], d['outputs_finite'], {k: round(s[k]['ms_per_step'],3) for k in keys if k in s})
+except Exception as e:
+    print('$name', 'FAILED', repr(e))"
+}
+{
+for rep in 1 2; do
+  ab default       CACO_DUMMY=0
+  ab attn_small    CACO_ATTN_SMALL=1
+  ab pos_fuse      CACO_POS_FUSE=1
+  ab both          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1
+  ab ngroup_off    CACO_W_NGROUP=0
+done
+} | tee "$OUT/ab.txt"
+bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
+CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
+cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
+echo "session done"

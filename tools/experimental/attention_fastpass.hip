@@ -361,6 +361,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
         *reinterpret_cast<bf16x4*>(stage + l31 * OPITCH + (dt * 32 + g * 8 + 4 * hf) * 2) = v;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CACO_WAVE_LDS_SYNC();
     const int rows_valid = min(32, Sq - qx);
     const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
         out + (qrow_base + qx) * H + h * HD, 0, (rows_valid - 1) * H * 2 + RP, 0x00020000);    // rows past Sq fall outside
@@ -372,6 +373,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       __builtin_amdgcn_raw_buffer_store_b128(v, out_r, r * H * 2 + c * 16, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staging block is reused by the next query block
+    CACO_WAVE_LDS_SYNC();
   }
 }
 

@@ -57,7 +57,15 @@ def _newer(out, deps):
     return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
 
 
-def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, verbose: bool = True) -> str:
+def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, verbose: bool = True, replace=None, defines=(),
+          tag: str = "") -> str:
+    """replace = {"attention.hip": "/path/to/variant.hip"}: a kernel source swapped for an experimental one (tools/experimental),
+    defines = ("-DATTN_FAST_PASS", ...): extra compiler flags; both need a `tag` (object files and library are kept apart)."""
+    replace = dict(replace or {})
+    if (replace or defines) and not tag:
+        raise ValueError("a variant build needs a tag")
+    if tag and lib == LIB:
+        lib = os.path.join(HERE, f"libcaco_sim_{tag}.so")
     os.makedirs(GEN, exist_ok=True)
     os.makedirs(os.path.join(SHIM, "hip"), exist_ok=True)
     shim = os.path.join(SHIM, "hip", "hip_runtime.h")
@@ -66,16 +74,18 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
             f.write('// stands in for <hip/hip_runtime.h> in the wavesim build\n#pragma once\n#include "wavesim.h"\n')
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
         os.path.join(HERE, "wavesim.h"), os.path.join(INCLUDE, "caco_hip.h"), os.path.abspath(__file__)]
-    flags = FLAGS + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
-    tag = ".asan" if asan else ""
+    flags = FLAGS + list(defines) + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
+    tag = ("." + tag if tag else "") + (".asan" if asan else "")
 
     def one(src):
         path = src if os.path.isabs(src) else os.path.join(CSRC, src)
         base = os.path.basename(path)
+        if base in replace:
+            path = replace[base]
         obj = os.path.join(GEN, base.replace(".hip", tag + ".o").replace(".cpp", tag + ".o"))
         if not force and _newer(obj, [path] + headers):
             return obj
-        gen = os.path.join(GEN, base.replace(".hip", ".cpp"))
+        gen = os.path.join(GEN, base.replace(".hip", tag + ".cpp"))
         if base.endswith(".hip"):
             with open(path) as f:
                 t = translate(f.read())

@@ -72,6 +72,8 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
   const void* main_stack_bottom = nullptr;      // ASan: the scheduler's own stack, learnt at the first switch into a lane
   size_t main_stack_size = 0;
   const std::function<void()>* body = nullptr;
+  int bar_gen = 0;                              // completed workgroup barriers of the running block
+  int bar_or[2] = {0, 0};                       // __syncthreads_or accumulators, by barrier parity
   ~Worker() {
     if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
     free(lanes);
@@ -148,6 +150,8 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
     for (int i = 3; i <= 8; ++i) f[-i] = nullptr;
     L.sp = &f[-8];
   }
+  W.bar_gen = 0;
+  W.bar_or[0] = W.bar_or[1] = 0;
   int live = nthreads;
   while (live > 0) {
     bool progress = false;
@@ -191,6 +195,8 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
     if (at_barrier > 0) {
       for (int t = 0; t < nthreads; ++t)
         if (W.lanes[t].state == 2) W.lanes[t].state = 0;
+      ++W.bar_gen;
+      W.bar_or[W.bar_gen & 1] = 0;              // the accumulator of the NEXT barrier; the released lanes read the other one
       progress = true;
     }
     if (!progress && live > 0) fail("deadlock in block (%u,%u,%u)", bidx.x, bidx.y, bidx.z);
@@ -210,6 +216,14 @@ void wave_rendezvous(const void* site) {
 void block_barrier() {
   cur->state = 2;
   yield_to_scheduler();
+}
+
+int block_barrier_or(int pred) {
+  Worker& W = *tl_w;
+  const int slot = W.bar_gen & 1;
+  if (pred) W.bar_or[slot] = 1;
+  block_barrier();
+  return W.bar_or[slot];
 }
 
 char* dyn_lds() { return tl_w->lds; }

@@ -80,6 +80,7 @@ extern int dma_late;                            // 1 = LDS-DMA bytes land at the
 
 void wave_rendezvous(const void* site);         // returns when every live lane of the wave has arrived at `site`
 void block_barrier();
+int block_barrier_or(int pred);                 // __syncthreads_or: barrier + OR of every live lane's predicate
 char* dyn_lds();                                // the workgroup's dynamic LDS (160 KiB)
 void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body);
 [[noreturn]] void fail(const char* fmt, ...);
@@ -197,6 +198,7 @@ static inline __attribute__((noinline)) void wavesim_wave_sync() { wavesim::wave
 static inline __attribute__((noinline)) void __builtin_amdgcn_wave_barrier() { wavesim::wave_rendezvous(__builtin_return_address(0)); }
 static inline void __builtin_amdgcn_s_barrier() { wavesim::block_barrier(); }
 static inline void __syncthreads() { wavesim::vm_wait(0); wavesim::block_barrier(); }
+static inline int __syncthreads_or(int pred) { wavesim::vm_wait(0); return wavesim::block_barrier_or(pred); }
 
 template <typename T>
 static inline T wavesim_exchange_from(T v, int src_lane, const void* site) {

@@ -188,6 +188,7 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   }
   // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 2256 = 256x128 two workgroups per CU
   if (cfg == 8256 && gemm_bf16_w8_ok(p, epi)) return gemm_bf16_w8(p, epi, act, st);
+  if (cfg == 4256 && gemm_bf16_w8_ok(p, epi) && p.bias) return gemm_bf16_w4q(p, epi, act, st);     // experiment: 4 waves of 128 x 128
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
   if (cfg == 256) {
     // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w8.hip: most reuse per L2 byte) when every
@@ -223,7 +224,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256) g_tile_cfg = tile;   // > 256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256 || tile == 4256) g_tile_cfg = tile;   // > 256: force a kernel
   return gemm_tile_config();
 }
 

@@ -1,0 +1,250 @@
+// gemm_bf16_w4q: the persistent 256x256x64 bf16 GEMM of gemm_w8.hip with FOUR waves per workgroup (2 x 2), each owning a
+// 128 x 128 part = 8 x 8 blocks of v_mfma_f32_16x16x32_bf16 (256 accumulator registers, one wave per SIMD, 512 registers).
+//
+// Why it exists (round-2 verdict item 2d): the vendor library's kernel for the fc1 shape runs this wave shape and issues
+// 0.59x the LDS instructions of w8 for the same MFMA work (profiles/r2_v3/pmc_hipblaslt_fc1_sq2.csv): a 128 x 128 wave tile
+// reads 8 + 8 fragments per 64 MFMAs (0.25 per MFMA), the 128 x 64 tile of w8 8 + 4 per 32 (0.375).  Fragment reads were
+// 0.05 of the 0.51 J of a fc1 launch in round 2's energy ablation, and these GEMMs run at the package power cap.
+// What it gives up: the second wave per SIMD that fills w8's stalls; every bubble of the single wave is a bubble of the
+// matrix pipe.  The 32x32x16 form of this shape lost against w8 in round 1; this is the 16x16x32 form on the rotated
+// K-loop of w8, written in round 3 WITHOUT a GPU: selectable with caco_set_gemm_tile(4256) only, never picked by default,
+// verified on the wavesim build (tests/test_wavesim.py) - not yet timed.
+//
+//   LDS, DMA, swizzle, tile order, epilogue: gemm_w8_common.h / gemm_w8_epilogue.h (the epilogue runs once per 64-column
+//   half of the wave's part).
+//   K-loop, four phases of 32 MFMAs per 64-deep K-tile (s0, s1 = the two 32-deep steps):
+//     P0: X(s0, 0..3) x W(s0, 0..7)    reads X(s0, 4..7), W(s1, 0..3)
+//     P1: X(s0, 4..7) x W(s0)          reads X(s1, 0..3), W(s1, 4..7)      A(g+2) pieces 0..3
+//     P2: X(s1, 0..3) x W(s1)          reads X(s1, 4..7)                   A(g+2) pieces 4..7
+//     -- vmcnt(8) lgkmcnt(0) s_barrier: every read of A(g), W(g) is done; A(g+1), W(g+1) have landed --
+//     P3: X(s1, 4..7) x W(s1)          reads X'(s0, 0..3), W'(s0, 0..7)    W(g+2) pieces 0..7 -> slot of W(g)
+//   Registers: 256 accumulators + two X sets of 4 and two W sets of 8 fragments (96) = 352 + addressing.
+//
+// Reference ops replaced: as gemm_w8.hip.
+#include "common.h"
+#include "kernels.h"
+#include "gemm_w8_common.h"
+#include "gemm_w8_epilogue.h"
+
+namespace caco {
+namespace {
+
+#define Q16_MFMAS(XC, WC, IB)                                                                                 \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                            \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                            \
+    acc[j_ >> 2][(IB) * 4 + q_][j_ & 3] =                                                                     \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[j_ >> 2][(IB) * 4 + q_][j_ & 3], 0, 0, 0);
+// interleave of one phase: 32 MFMAs, the first NRD of them followed by a fragment read, VMEM after the MFMAs in VM_MASK
+#define Q16_SCHED(NRD, VM_MASK)                                                                               \
+  _Pragma("unroll") for (int n_ = 0; n_ < 32; ++n_) {                                                         \
+    __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                                  \
+    if (n_ < (NRD)) __builtin_amdgcn_sched_group_barrier(W4_SGB_DSRD, 1, 0);                                  \
+    if (((VM_MASK) >> n_) & 1u) __builtin_amdgcn_sched_group_barrier(W4_SGB_VMEM, 1, 0);                      \
+  }                                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
+template <int EPI, int ACT, int MODE>
+__device__ __forceinline__ void q16_body(const GemmArgs& p, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lda = p.lda ? p.lda : p.K, ldw = p.ldw ? p.ldw : p.K;
+
+  const int tiles_n = p.N / 256;
+  const int tiles_m = (int)((p.M + 255) / 256);
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  if (slot >= cnt) return;
+  const int nk = p.K / WBK;
+
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int x_off = wm * 128 * WROWB, w_off = wn * 128 * WROWB;
+
+  W4CurA<4> CA;
+  W4CurW CW;
+  CA.li = CW.li = slot;
+  CA.kt = CW.kt = 0;
+  w4_setup_a<4>(CA, p, base + slot, tiles_n, lda, wave, lane);
+  w4_setup_w(CW, p, base + slot, tiles_n, ldw, wave, lane);
+  auto advance_a = [&]() {
+    if (++CA.kt == nk) {
+      CA.kt = 0;
+      if (CA.li + slots < cnt) { CA.li += slots; w4_setup_a<4>(CA, p, base + CA.li, tiles_n, lda, wave, lane); }
+    }
+  };
+  auto advance_w = [&]() {
+    if (++CW.kt == nk) {
+      CW.kt = 0;
+      if (CW.li + slots < cnt) { CW.li += slots; w4_setup_w(CW, p, base + CW.li, tiles_n, ldw, wave, lane); }
+    }
+  };
+
+  int a_c = W_AOFF, a_1 = W_AOFF + W_SLOT, a_2 = W_AOFF + 2 * W_SLOT;
+  int w_c = W_WOFF, w_1 = W_WOFF + W_SLOT;
+
+  // prologue: A(0) W(0) | A(1) W(1): 8 pieces per wave and operand K-tile
+#pragma unroll
+  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_c, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
+  advance_w();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_1, wave);
+  advance_a();
+#pragma unroll
+  for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_1, wave);
+  advance_w();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#define Q16_F(OPER, BLK, S) w4_frag(OPER, (BLK) * 16 + l16, (S) * 4 + lq)
+  bf16x8 xa[4], xb[4], wc[8], wn_[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xa[i] = Q16_F(smem + a_c + x_off, i, 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wc[j] = Q16_F(smem + w_c + w_off, j, 0);
+
+  constexpr int NST = (EPI == EPI_BF16) ? 32 : 64;      // global stores per wave and epilogue (both halves, full tile)
+  constexpr int WAIT_ST = (8 + NST > 63) ? 63 : 8 + NST;   // vmcnt is a 6-bit field: a smaller count only waits for more
+  bool stores_pending = false;
+  int c_li = slot;
+  while (true) {
+    f32x4 acc[2][8][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][i][j][e] = 0.f;
+#ifndef WAVESIM
+    // The 256 accumulators must LIVE in the AGPR half of the register file (only v0..v255 and a0..a255 are addressable; the
+    // fragments and addresses need the VGPR half).  Left alone, hipcc 7.2 carries them through the K-loop in VGPRs and
+    // copies every MFMA's C operand in and its result out (436 v_accvgpr_write + 212 v_accvgpr_read per K-tile); pinning
+    // each tuple to the "a" class once per output tile makes the loop-carried values AGPRs.
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+#endif
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* xs = smem + a_c + x_off;
+      const char* ws = smem + w_c + w_off;
+      // P0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xb[i] = Q16_F(xs, 4 + i, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wn_[j] = Q16_F(ws, j, 1);
+      Q16_MFMAS(xa, wc, 0)
+      Q16_SCHED(8, 0u)
+      // P1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xa[i] = Q16_F(xs, i, 1);
+#pragma unroll
+      for (int j = 4; j < 8; ++j) wn_[j] = Q16_F(ws, j, 1);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) w4_piece_a<4>(CA, it, smem + a_2, wave);
+      Q16_MFMAS(xb, wc, 1)
+      Q16_SCHED(8, (1u << 4) | (1u << 12) | (1u << 20) | (1u << 28))
+      // P2
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xb[i] = Q16_F(xs, 4 + i, 1);
+#pragma unroll
+      for (int it = 4; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_2, wave);
+      Q16_MFMAS(xa, wn_, 0)
+      Q16_SCHED(4, (1u << 4) | (1u << 12) | (1u << 20) | (1u << 28))
+      advance_a();
+      if (stores_pending) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAIT_ST) : "memory");
+        stores_pending = false;
+      } else {
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // P3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xa[i] = Q16_F(smem + a_1 + x_off, i, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wc[j] = Q16_F(smem + w_1 + w_off, j, 0);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
+      Q16_MFMAS(xb, wn_, 1)
+      Q16_SCHED(12, (1u << 2) | (1u << 6) | (1u << 10) | (1u << 14) | (1u << 18) | (1u << 22) | (1u << 26) | (1u << 30))
+      advance_w();
+      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
+      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+    }
+    const int t = base + c_li;
+    int tm_, tn_;
+    w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);
+    const int64_t m_cur = (int64_t)tm_ * 256;
+    const int n_cur = tn_ * 256;
+    // the epilogue of gemm_w8 handles a 128 x 64 part: once per 64-column half, through this wave's 4 KiB of the free A slot
+#pragma unroll
+    for (int h = 0; h < 2; ++h) w16_epilogue<EPI, ACT, MODE>(acc[h], p, m_cur, n_cur, wm, wn * 2 + h, lane, smem + a_2 + wave * 4096);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa[i] = Q16_F(smem + a_c + x_off, i, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wc[j] = Q16_F(smem + w_c + w_off, j, 0);
+    stores_pending = (EPI == EPI_F32) && (MODE != 0 || !p.xb_out == !p.stats_part);
+    c_li += slots;
+    if (c_li >= cnt) break;
+  }
+}
+
+template <int EPI, int ACT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4q_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  q16_body<EPI, ACT, MODE>(p, smem);
+}
+
+template <int EPI, int ACT, int MODE>
+int launch_w4q(const GemmArgs& p, hipStream_t st) {
+  void (*kern)(GemmArgs) = gemm_bf16_w4q_kernel<EPI, ACT, MODE>;
+  int num_cu = 0;
+  CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), W_SMEM, &num_cu));
+  const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
+  const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
+  GemmArgs q = p;
+  const int tiles_n = p.N / 256;
+  q.ngroup = tiles_n;
+  if (tiles_n > 4 && p.K <= 1024) {            // the same n-tile groups as gemm_w8
+    q.ngroup = 4;
+    for (int d = 4; d >= 2; --d)
+      if (tiles_n % d == 0) { q.ngroup = d; break; }
+  }
+  q.stagger = 0;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W_SMEM, st, q);
+  return check_hip(hipGetLastError(), "gemm_bf16_w4q launch");
+}
+
+}  // namespace
+
+// the plain forms only (bias; bias + residual): the experiment is about the K-loop.  Anything else: CACO_ERR_INVALID.
+int gemm_bf16_w4q(const GemmArgs& p, int epi, int act, hipStream_t st) {
+  CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16_w4q: shape not supported");
+  CACO_REQUIRE(p.bias && !p.fold_mr && !p.xb_out && !p.stats_part && !p.resid_idx, "gemm_bf16_w4q: plain epilogues only");
+  if (epi == EPI_BF16 && !p.resid) {
+    if (act == ACT_NONE) return launch_w4q<EPI_BF16, ACT_NONE, 1>(p, st);
+    if (act == ACT_SILU) return launch_w4q<EPI_BF16, ACT_SILU, 1>(p, st);
+    if (act == ACT_GELU) return launch_w4q<EPI_BF16, ACT_GELU, 1>(p, st);
+  }
+  if (epi == EPI_F32 && act == ACT_NONE) {
+    if (p.resid) return launch_w4q<EPI_F32, ACT_NONE, 2>(p, st);
+    return launch_w4q<EPI_F32, ACT_NONE, 1>(p, st);
+  }
+  set_error("gemm_bf16_w4q: unsupported epilogue %d / activation %d", epi, act);
+  return CACO_ERR_INVALID;
+}
+
+}  // namespace caco

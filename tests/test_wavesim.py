@@ -38,7 +38,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
-@pytest.mark.parametrize("tile", [128, 2256, 8256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
 @pytest.mark.parametrize("M,N,K,act", [(300, 256, 128, 0), (520, 768, 256, 1), (257, 512, 192, 2), (64, 256, 64, 0)])
 def test_gemm_bf16(sim, tile, M, N, K, act):
     assert sim.caco_set_gemm_tile(tile) == tile
@@ -55,7 +55,7 @@ def test_gemm_bf16(sim, tile, M, N, K, act):
     sim.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [128, 2256, 8256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
 def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(tile)
     M, N, K = 301, 768, 192
@@ -72,11 +72,13 @@ def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(256)
 
 
+@pytest.mark.parametrize("tile", [8256, 4256], ids=["w8", "w4q"])
 @pytest.mark.parametrize("kind", ["f32r", "bf16", "silu"])
-def test_gemm_w8_persistent_multi_tile_pipeline(sim, kind):
+def test_gemm_w8_persistent_multi_tile_pipeline(sim, kind, tile):
     """More output tiles than workgroups (the simulator reports 16 CUs): operand loads prefetched across output-tile
-    boundaries, the counted wait that leaves an epilogue's stores in flight, a ragged last M tile in mid-pipeline."""
-    sim.caco_set_gemm_tile(8256)
+    boundaries, the counted wait that leaves an epilogue's stores in flight, a ragged last M tile in mid-pipeline.
+    w4q = the four-wave 128 x 128-per-wave experiment (gemm_w4q.hip, tile code 4256)."""
+    assert sim.caco_set_gemm_tile(tile) == tile
     M, N, K = 1900, 768, 256          # 8 x 3 = 24 tiles on 16 workgroups
     a = _rand((M, K), 11).bfloat16()
     w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()

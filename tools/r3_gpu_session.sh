@@ -40,5 +40,6 @@ bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs 
 CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
 cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
+{ for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
 echo "session done"

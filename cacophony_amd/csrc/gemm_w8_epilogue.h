@@ -25,7 +25,12 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 //   5 bias + GATHERED residual (EPI_F32): row m adds resid[resid_idx[m], :] of a small table (row stride ldc); an index
 //     < 0 wraps past the descriptor's range and reads as 0.  The patch-embed GEMM's positional embedding (api.hip).
 // Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
-// fall outside num_records, so stores need no exec mask and always count NST in vmcnt.
+// fall outside num_records, so stores need no exec mask and always count NST in vmcnt.  The ROW part of every offset is in
+// the per-lane (VGPR) offset: that is the only part the hardware range-checks - the scalar offset operand is "excluded
+// from bounds checking" (LLVM's definition of the raw.buffer intrinsics).  Rounds 1-2 stepped through the row blocks with
+// the scalar offset, which leaves the rows of a ragged last M tile unprotected (found in round 3 on the wavesim build once
+// its descriptor model followed that definition: heap corruption at M % 256 != 0); only the column half j * 128, which is
+// always inside a valid row's 256-byte span, still rides in the scalar offset.
 // (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
 // the epilogue - is 30-40 % SLOWER on the QKV / fc1 shapes: partial-line writes from 32 rows per instruction.)
 // Cache-policy bits of the epilogue's stores / residual loads: 2 = nt (streaming).  The outputs are far larger than the
@@ -52,6 +57,15 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 // bf16: per 32-row block row a 32 x 64 bf16 slab.  Bias (and the LayerNorm-fold column sums) are re-read from L1 per
 // 4-column group instead of being held in 32-64 registers across the whole epilogue: the accumulators already fill half
 // the register file.  fp32: eight 32 x 32 fp32 slabs, the residual of slab s+1 fetched while slab s is processed.
+// The per-lane offsets voff + block * rowb are loop-invariant across the output tiles of a persistent workgroup; left alone
+// the compiler hoists all 16 of them out of the tile loop and carries 14 more VGPRs through the K-loop (238 -> 252 of the
+// 256 a two-waves-per-SIMD kernel has).  Making the row pitch opaque once per epilogue keeps them epilogue-local: one
+// v_add with a scalar operand per access instead.
+#ifdef WAVESIM
+#define W8_EPI_LOCAL(x) ((void)0)
+#else
+#define W8_EPI_LOCAL(x) asm volatile("" : "+s"(x))
+#endif
 template <int EPI, int ACT, int MODE>
 __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const GemmArgs& p, int64_t m0, int n0, int wm, int wn, int lane, char* slab) {
   const int l16 = lane & 15, lq = lane >> 4;
@@ -61,7 +75,8 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
   const int rows = (int)min((int64_t)128, p.M - mw);    // valid rows of this wave's part (may be <= 0)
   const bool has_bias = MODE ? true : p.bias != nullptr;
   if constexpr (EPI == EPI_BF16) {
-    const int rowb = p.ldc * 2;
+    int rowb = p.ldc * 2;
+    W8_EPI_LOCAL(rowb);
     const __amdgpu_buffer_rsrc_t out_r = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<bf16_t*>(p.out) + mw * p.ldc + nw, 0, rows > 0 ? (rows - 1) * rowb + 128 : 0, 0x00020000);
     const int voff = rrow * rowb + c8 * 16;
@@ -118,12 +133,13 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff, (i * 32 + tt * 8) * rowb, W8_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff + (i * 32 + tt * 8) * rowb, 0, W8_ST_AUX);
       }
       CACO_WAVE_LDS_SYNC();
     }
   } else {   // EPI_F32: eight 32 x 32 fp32 slabs; the residual of slab s+1 is fetched while slab s is processed
-    const int rowb = p.ldc * 4;
+    int rowb = p.ldc * 4;
+    W8_EPI_LOCAL(rowb);
     const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
     const bool has_resid = MODE ? (MODE == 2 || MODE == 4 || MODE == 5) : p.resid != nullptr;
     const bool produce_xb = MODE ? MODE == 4 : p.xb_out != nullptr;
@@ -152,7 +168,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         if constexpr (MODE == 5) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, gidx[i][tt] * rowb + c8 * 16, j * 128, 0);   // table rows are re-used: default cache policy
-        else dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_LD_AUX);
+        else dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff + (i * 32 + tt * 8) * rowb, j * 128, W8_LD_AUX);
       }
     };
     if (has_resid) {
@@ -178,13 +194,13 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
         const int row = tt * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
         if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff, (i * 32 + tt * 8) * rowb + j * 128, W8_ST_AUX_F32);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff + (i * 32 + tt * 8) * rowb, j * 128, W8_ST_AUX_F32);
         if (produce_xb) {
           bf16x4 b;
 #pragma unroll
           for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff >> 1), ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff + (i * 32 + tt * 8) * rowb) >> 1, (j * 128) >> 1, 0);
         }
         if (produce_st) {
           const float a1 = (v[0] + v[1]) + (v[2] + v[3]);

@@ -548,3 +548,21 @@ def test_token_group_mean_and_strided_similarity(sim):
     simlib.check(sim.caco_similarity_ld(P(bank[:, 0]), 9, 2 * 768, P(bank[:, 1]), 9, 2 * 768, 768, 2.0, P(sim_m), 12, None))
     ref = 2.0 * bank[:, 0].double() @ bank[:, 1].double().T
     assert (sim_m[:, :9].double() - ref).abs().max().item() < 1e-5 and torch.isnan(sim_m[:, 9:]).all()
+
+
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
+def test_gemm_ragged_m_writes_nothing_past_row_m(sim, tile):
+    """tests/test_gpu_ops.py::test_gemm_ragged_m_writes_nothing_past_row_m on the simulator, whose buffer descriptors
+    range-check the per-lane offset only (as the hardware does): guard rows behind the output keep their sentinel."""
+    sim.caco_set_gemm_tile(tile)
+    M, N, K, G = 300, 768, 128, 256
+    a = _rand((M, K), 1).bfloat16()
+    w = _rand((N, K), 2, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 3)
+    out = torch.full((M + G, N), 7.0, dtype=torch.bfloat16)
+    simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, 1, P(out), None))
+    x = torch.full((M + G, N), 7.0)
+    x[:M] = _rand((M, N), 4)
+    simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(x), None))
+    assert (out[M:] == 7.0).all() and (x[M:] == 7.0).all()
+    sim.caco_set_gemm_tile(256)

@@ -20,7 +20,7 @@
 //   * __syncthreads() = s_waitcnt vmcnt(0) + barrier (what hipcc emits); __builtin_amdgcn_s_barrier() is the bare barrier
 //   * LDS is ordinary host memory: `__shared__` becomes a thread_local static (one workgroup per OS thread at a time)
 //   * raw buffer descriptors: base + byte range; accesses are range-checked per dword like the hardware (loads of
-//     out-of-range dwords return 0, stores are dropped)
+//     out-of-range dwords return 0, stores are dropped) - on the per-lane offset only: the scalar offset is outside the check
 //   * MFMA numerics: exact products of the bf16 / fp32 inputs accumulated in fp32 in k order (the hardware's internal
 //     order is unspecified; differences are below the tests' tolerances)
 //
@@ -264,36 +264,41 @@ static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* bas
   return __amdgpu_buffer_rsrc_t{reinterpret_cast<char*>(base), (uint32_t)num_records};
 }
 typedef unsigned int wavesim_u32x4 __attribute__((ext_vector_type(4)));
-static inline void wavesim_buffer_read(const __amdgpu_buffer_rsrc_t& r, int64_t off, void* dst, int bytes) {
+// Raw buffer addressing: address = base + soffset + (voffset + imm); the RANGE CHECK covers voffset + imm only - the scalar
+// offset is "excluded from bounds checking" (LLVM's definition of the raw.buffer intrinsics' soffset operand, and the reason
+// composable_kernel's out-of-bounds trick adds 0x80000000 to the per-lane offset, ck/utility/amd_buffer_addressing.hpp).
+// A kernel that steps through rows with soffset gets NO protection for the rows it reaches that way: under this model such
+// an access goes to memory, where AddressSanitizer (asan_check.py) sees it.
+static inline void wavesim_buffer_read(const __amdgpu_buffer_rsrc_t& r, uint32_t checked_off, uint32_t soff, void* dst, int bytes) {
   unsigned char* d = reinterpret_cast<unsigned char*>(dst);
   for (int b = 0; b < bytes; b += 4) {
-    const int64_t o = off + b;
-    if (o >= 0 && o + 4 <= (int64_t)r.num_records) memcpy(d + b, r.base + o, 4);
+    const int64_t o = (int64_t)checked_off + b;
+    if (o + 4 <= (int64_t)r.num_records) memcpy(d + b, r.base + o + soff, 4);
     else memset(d + b, 0, 4);
   }
 }
-static inline void wavesim_buffer_write(const __amdgpu_buffer_rsrc_t& r, int64_t off, const void* src, int bytes) {
+static inline void wavesim_buffer_write(const __amdgpu_buffer_rsrc_t& r, uint32_t checked_off, uint32_t soff, const void* src, int bytes) {
   const unsigned char* s = reinterpret_cast<const unsigned char*>(src);
   for (int b = 0; b < bytes; b += 4) {
-    const int64_t o = off + b;
-    if (o >= 0 && o + 4 <= (int64_t)r.num_records) memcpy(r.base + o, s + b, 4);
+    const int64_t o = (int64_t)checked_off + b;
+    if (o + 4 <= (int64_t)r.num_records) memcpy(r.base + o + soff, s + b, 4);
   }
 }
 static inline wavesim_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
   (void)aux;
   wavesim_u32x4 v;
-  wavesim_buffer_read(r, (int64_t)(uint32_t)voff + (uint32_t)soff, &v, 16);
+  wavesim_buffer_read(r, (uint32_t)voff, (uint32_t)soff, &v, 16);
   wavesim::vm_push(nullptr, nullptr, 0);
   return v;
 }
 static inline void __builtin_amdgcn_raw_buffer_store_b128(wavesim_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
   (void)aux;
-  wavesim_buffer_write(r, (int64_t)(uint32_t)voff + (uint32_t)soff, &v, 16);
+  wavesim_buffer_write(r, (uint32_t)voff, (uint32_t)soff, &v, 16);
   wavesim::vm_push(nullptr, nullptr, 0);
 }
 static inline void __builtin_amdgcn_raw_buffer_store_b64(wavesim_u32x2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int aux) {
   (void)aux;
-  wavesim_buffer_write(r, (int64_t)(uint32_t)voff + (uint32_t)soff, &v, 8);
+  wavesim_buffer_write(r, (uint32_t)voff, (uint32_t)soff, &v, 8);
   wavesim::vm_push(nullptr, nullptr, 0);
 }
 typedef __attribute__((address_space(3))) void* wavesim_lds_vptr;
@@ -304,7 +309,7 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc
   (void)aux;
   unsigned char tmp[16];
   if (size > 16) wavesim::fail("buffer_load ... lds of %d bytes", size);
-  wavesim_buffer_read(r, (int64_t)(uint32_t)voff + (uint32_t)soff + (uint32_t)imm, tmp, size);
+  wavesim_buffer_read(r, (uint32_t)voff + (uint32_t)imm, (uint32_t)soff, tmp, size);
   wavesim::vm_push(reinterpret_cast<char*>((uintptr_t)lds) + wavesim::cur->lane * size, tmp, size);
 }
 typedef __attribute__((address_space(1))) void* wavesim_glb_vptr;

@@ -566,3 +566,37 @@ def test_gemm_ragged_m_writes_nothing_past_row_m(sim, tile):
     simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(x), None))
     assert (out[M:] == 7.0).all() and (x[M:] == 7.0).all()
     sim.caco_set_gemm_tile(256)
+
+
+def test_results_do_not_depend_on_the_schedule(sim, monkeypatch):
+    """The same launches with waves and lanes run first-to-last and last-to-first between rendezvous points, and with LDS-DMA
+    landing late (at the covering wait) and at once: bitwise the same outputs.  A kernel that only works because wave 0
+    happens to run first (a missing barrier, a read of another wave's data before its covering wait) would differ."""
+    M, N, K = 700, 768, 192
+    a = _rand((M, K), 1).bfloat16()
+    w = _rand((N, K), 2, 1.0 / math.sqrt(K)).bfloat16()
+    bias = _rand((N,), 3)
+    B, S, heads, hd = 2, 200, 2, 96
+    qkv = _rand((B, S, 3 * heads * hd), 4, 1.2).bfloat16()
+    mask = torch.ones(B, S)
+    mask[1, 150:] = 0
+    wav = torch.from_numpy(synth.make_waveforms(1, n_samples=20000))
+    outs = {}
+    for order in ("forward", "reverse"):
+        monkeypatch.setenv("WAVESIM_ORDER", order)
+        got = []
+        for tile in (8256, 4256, 2256):
+            sim.caco_set_gemm_tile(tile)
+            o = torch.empty(M, N, dtype=torch.bfloat16)
+            simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, 1, P(o), None))
+            x = _rand((M, N), 5)
+            simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(x), None))
+            got += [o, x]
+        sim.caco_set_gemm_tile(256)
+        o = torch.empty(B, S, heads * hd, dtype=torch.bfloat16)
+        simlib.check(sim.caco_op_attention(P(qkv), 3 * heads * hd, heads * hd, 2 * heads * hd, P(mask), B, S, heads, hd, 0, P(o), None))
+        got.append(o)
+        got.append(_mel_patches(sim, wav, 80)["audio_patches"])
+        outs[order] = got
+    for x, y in zip(outs["forward"], outs["reverse"]):
+        assert torch.equal(x.float(), y.float())

@@ -56,6 +56,13 @@ namespace wavesim {
 WAVESIM_TLS Lane* cur = nullptr;
 WAVESIM_TLS idx3 block_idx = {0, 0, 0}, block_dim = {1, 1, 1}, grid_dim = {1, 1, 1};
 int dma_late = [] { const char* e = getenv("WAVESIM_DMA"); return (e && !strcmp(e, "eager")) ? 0 : 1; }();
+// WAVESIM_ORDER=reverse: waves (and the lanes inside a wave) are run last to first between rendezvous points.  Results must
+// not depend on it: a kernel that only works because wave 0 happens to run first (a missing barrier, a read of another
+// wave's LDS data before its covering wait) gives different bytes under the other order.
+static int order_reverse() {
+  const char* e = getenv("WAVESIM_ORDER");      // read per launch: tests flip it at run time
+  return e && !strcmp(e, "reverse");
+}
 
 namespace {
 
@@ -152,15 +159,18 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
   }
   W.bar_gen = 0;
   W.bar_or[0] = W.bar_or[1] = 0;
+  const int rev = order_reverse();
   int live = nthreads;
   while (live > 0) {
     bool progress = false;
     int at_barrier = 0;
     live = 0;
-    for (int w = 0; w < nwaves; ++w) {
+    for (int wi = 0; wi < nwaves; ++wi) {
+      const int w = rev ? nwaves - 1 - wi : wi;
       Wave& wv = W.waves[w];
       for (;;) {
-        for (int l = 0; l < wv.nlanes; ++l) {
+        for (int li = 0; li < wv.nlanes; ++li) {
+          const int l = rev ? wv.nlanes - 1 - li : li;
           Lane* L = wv.lanes[l];
           while (L->state == 0) {
             cur = L;

@@ -600,3 +600,67 @@ def test_results_do_not_depend_on_the_schedule(sim, monkeypatch):
         outs[order] = got
     for x, y in zip(outs["forward"], outs["reverse"]):
         assert torch.equal(x.float(), y.float())
+
+
+def test_bad_arguments_are_refused_not_executed(sim, tiny_state):
+    """Every entry point with arguments it cannot serve returns a status and a message - on the simulator a missing check
+    would dereference a null / run a kernel off its buffers and take the process down (tests/test_abi.py covers the calls
+    that need no device; these need one)."""
+    import ctypes
+    z = torch.zeros(64, 768)
+    zb = torch.zeros(64, 768, dtype=torch.bfloat16)
+    bad = []
+
+    def refused(rc, what):
+        if rc == 0:
+            bad.append(what)
+        else:
+            assert sim.caco_last_error(), what
+
+    refused(sim.caco_op_gemm_bf16(P(zb), P(zb), None, 64, 100, 768, 0, P(zb), None), "gemm N % 128")
+    refused(sim.caco_op_gemm_bf16(P(zb), P(zb), None, 64, 128, 100, 0, P(zb), None), "gemm K % 64")
+    refused(sim.caco_op_gemm_bf16(P(zb), P(zb), None, 0, 128, 64, 0, P(zb), None), "gemm M = 0")
+    refused(sim.caco_op_gemm_bf16(None, P(zb), None, 64, 128, 64, 0, P(zb), None), "gemm null A")
+    refused(sim.caco_op_gemm_bf16(P(zb), P(zb), None, 64, 128, 64, 7, P(zb), None), "gemm unknown activation")
+    refused(sim.caco_op_gemm_bf16_strided(P(zb), 60, P(zb), 64, None, 64, 128, 64, 0, P(zb), 128, None), "gemm lda < K")
+    refused(sim.caco_op_attention(P(zb), 768, 256, 512, None, 1, 64, 4, 80, 0, P(zb), None), "attention head_dim 80")
+    refused(sim.caco_op_attention(P(zb), 770, 256, 512, None, 1, 64, 4, 64, 0, P(zb), None), "attention ld % 8")
+    refused(sim.caco_op_attention(None, 768, 256, 512, None, 1, 64, 4, 64, 0, P(zb), None), "attention null")
+    refused(sim.caco_op_attention(P(zb), 768, 256, 512, None, 0, 64, 4, 64, 0, P(zb), None), "attention batch 0")
+    refused(sim.caco_op_attention_qkv(P(zb), 256, 20, P(zb), 768, 256, 512, None, 1, 64, 4, 64, 1, P(zb), None), "causal with Sq != S")
+    refused(sim.caco_topk(P(z), 4, 16, 16, 1, 0, P(z), None, None), "topk k = 0")
+    refused(sim.caco_topk(P(z), 4, 16, 16, 1, 65, P(z), None, None), "topk k > 64")
+    refused(sim.caco_similarity(None, 4, P(z), 4, 768, 1.0, P(z), 4, None), "similarity null")
+    refused(sim.caco_similarity(P(z), 4, P(z), 4, 768, 1.0, P(z), 2, None), "similarity ld_out < nt")
+    refused(sim.caco_mel_patches(P(z), 1, 0, 16, 0.2, 0.9, P(z), 0, P(z), P(z), P(z), None), "mel n_samples 0")
+    refused(sim.caco_mel_patches(P(z), 1, 700, 16, 0.2, 0.9, P(z), 5, P(z), P(z), P(z), None), "mel dtype")
+    refused(sim.caco_token_group_mean(P(z), 1, 64, 766, 8, P(z), None), "group mean dim % 4")
+    # model-level: calls before the weights are final, on the wrong tower, with nulls
+    a, t, cc = C.tiny_configs(1)
+    m = simlib.SimModel(a, None, cc)
+    e = torch.zeros(2, 768)
+    refused(sim.caco_audio_forward(m.h, P(z), 0, P(z), P(z), P(z), 2, 8, 0, P(e), None, None), "audio forward before finalize")
+    m.load_state_dict({k: v for k, v in synth.make_caco_state(a, t, cc).items() if k.startswith("audio_")})
+    refused(sim.caco_audio_forward(m.h, None, 0, P(z), P(z), P(z), 2, 8, 0, P(e), None, None), "audio forward null patches")
+    refused(sim.caco_audio_forward(m.h, P(z), 0, P(z), P(z), P(z), 0, 8, 0, P(e), None, None), "audio forward batch 0")
+    ids = torch.zeros(2, 8, dtype=torch.int64)
+    refused(sim.caco_text_forward(m.h, P(ids), P(ids), None, 2, 8, 0, P(e), None, None), "text forward on an audio-only model")
+    refused(sim.caco_decoder_forward(m.h, P(z), P(ids), P(z), P(z), 2, 8, 8, P(z), None), "decoder not initialised")
+    st = ctypes.c_void_p()
+    refused(sim.caco_decode_begin(m.h, P(z), P(z), 2, 8, 4, ctypes.byref(st), None), "decode_begin without a decoder")
+    refused(sim.caco_mae_forward(m.h, P(z), 0, P(z), P(z), P(z), P(z), P(z), P(z), 2, 4, 4, P(z), None), "mae forward without a decoder")
+    refused(sim.caco_encode_audio_ex(m.h, P(z), None, 2, 0, 8, P(e), 0, None), "encode_audio n_samples 0")
+    refused(sim.caco_encode_audio_ex(m.h, P(z), None, 2, 700, 8, P(e), 100, None), "encode_audio ld_emb < projection")
+    cfg = _bad_config()
+    h = ctypes.c_void_p()
+    refused(sim.caco_create(ctypes.byref(cfg), ctypes.byref(h)), "create with 3 pool heads")
+    assert not bad, bad
+
+
+def _bad_config():
+    import ctypes
+    from cacophony_amd import _lib
+    cfg = _lib.CacoConfigC()
+    simlib.load().caco_default_config(ctypes.byref(cfg))
+    cfg.pool_heads = 3
+    return cfg

@@ -74,7 +74,9 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
   char* stacks = nullptr;
   Lane* lanes = nullptr;
   Wave* waves = nullptr;
-  char* lds = nullptr;
+  char* lds = nullptr;                          // this launch's dynamic LDS (inside lds_region)
+  char* lds_region = nullptr;
+  size_t lds_bytes = 0;
   void* main_sp = nullptr;
   const void* main_stack_bottom = nullptr;      // ASan: the scheduler's own stack, learnt at the first switch into a lane
   size_t main_stack_size = 0;
@@ -85,7 +87,7 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
     if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
     free(lanes);
     free(waves);
-    free(lds);
+    if (lds_region) munmap(lds_region, DYN_LDS + 4096);
   }
   void ensure() {
     if (stacks) return;
@@ -93,8 +95,12 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
     if (stacks == MAP_FAILED) fail("mmap of fiber stacks failed");
     lanes = (Lane*)calloc(MAX_THREADS, sizeof(Lane));
     waves = (Wave*)aligned_alloc(64, sizeof(Wave) * (MAX_THREADS / 64));
-    lds = (char*)aligned_alloc(256, DYN_LDS);
-    memset(lds, 0, DYN_LDS);
+    // dynamic LDS: DYN_LDS bytes followed by an inaccessible page.  A launch that declares n bytes gets the LAST n bytes
+    // before that page, so a kernel that touches more dynamic LDS than it asked for faults here as it would on the device.
+    lds_region = (char*)mmap(nullptr, DYN_LDS + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (lds_region == MAP_FAILED) fail("mmap of the LDS region failed");
+    mprotect(lds_region + DYN_LDS, 4096, PROT_NONE);
+    lds = lds_region;
   }
 };
 Worker g_workers[65];                 // slot 0: the launching thread itself; never torn down (reused by every launch)
@@ -122,10 +128,13 @@ void yield_to_scheduler() {
   WAVESIM_ASAN_FINISH(fake, nullptr, nullptr);
 }
 
-void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& body) {
+void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& body, size_t lds_bytes) {
   Worker& W = *tl_w;
   W.ensure();
   W.body = &body;
+  W.lds_bytes = (lds_bytes + 15) & ~(size_t)15;
+  W.lds = W.lds_region + DYN_LDS - W.lds_bytes;
+  memset(W.lds, 0xff, W.lds_bytes);             // LDS is not initialised on the device: unwritten bytes read as NaN patterns
   block_idx = bidx;
   block_dim = bdim;
   grid_dim = gdim;
@@ -272,7 +281,7 @@ void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>
       bi.x = (unsigned)(b % grid.x);
       bi.y = (unsigned)((b / grid.x) % grid.y);
       bi.z = (unsigned)(b / ((long)grid.x * grid.y));
-      run_block(bi, block, grid, body);
+      run_block(bi, block, grid, body, lds_bytes);
     }
   };
   static std::mutex launch_mu;           // one launch at a time: the worker slots are shared

@@ -477,8 +477,9 @@ def test_jax_side_hyperparameters_8_pool_heads_eps_1e6(tiny_state):
     r8 = o.get_audio_embedding(*args, normalize=True)[0]
     r2 = o2.get_audio_embedding(*args, normalize=True)[0]
     assert cosine_rows(emb, r8).min() > COS_TOL
-    mu = r8.mean(0, keepdims=True)
-    assert cosine_rows(emb - mu, r8 - mu).min() > cosine_rows(emb - mu, r2 - mu).max()
+    # the two head counts differ by 3.8 % in relative L2 on these clips (raw cosine 0.9992: the 1e-3 cosine bar alone would
+    # not tell them apart); the bf16 path's own error is several times smaller
+    assert rel_l2(emb, r8) < 0.5 * rel_l2(emb, r2)
 
 
 def test_unindexed_device_and_host_inputs_to_encode_pairs(tiny_state):

@@ -334,8 +334,7 @@ def test_jax_side_hyperparameters_8_pool_heads_eps_1e6(sim, tiny_state):
     assert cosine_rows(emb.numpy(), r_emb).min() > 0.999
     o2 = O.CacoOracle(tiny_state, a8, t, cc, backend="torch")
     r2, _ = o2.get_audio_embedding(host["audio_patches"], host["audio_time_inds"], host["audio_freq_inds"], host["audio_mask"], normalize=True)
-    mu = r_emb.mean(0, keepdims=True)
-    assert cosine_rows(emb.numpy() - mu, r_emb - mu).min() > cosine_rows(emb.numpy() - mu, r2 - mu).max()
+    assert rel_l2(emb.numpy(), r_emb) < 0.5 * rel_l2(emb.numpy(), r2)      # the two head counts differ by several per cent
 
 
 def test_mel_lengths_bound_the_sample_fetch(sim):

@@ -272,14 +272,15 @@ int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
   // compile-time specialised epilogues (w8_epilogue MODE): 1 bias only, 2 bias + residual, 3 bias + LayerNorm-fold consumer,
   // 4 bias + residual + fold producer (bf16 copy + row sums), 5 bias + gathered residual; 0 = generic (tested at run time)
   static const bool generic = getenv("CACO_W8_GENERIC") && atoi(getenv("CACO_W8_GENERIC"));
-  const bool plain = !generic && p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
+  const bool plain_args = p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
+  const bool plain = !generic && plain_args;
   if (plain && epi == EPI_BF16 && !p.resid) {
     if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE, 1>(p, st);
     if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU, 1>(p, st);
     if (act == ACT_GELU) return launch_w8<EPI_BF16, ACT_GELU, 1>(p, st);
   }
   if (p.resid_idx) {
-    CACO_REQUIRE(plain && epi == EPI_F32 && act == ACT_NONE && p.resid, "gemm_bf16_w8: a gathered residual needs bias, a residual table and the plain fp32 epilogue");
+    CACO_REQUIRE(plain_args && epi == EPI_F32 && act == ACT_NONE && p.resid, "gemm_bf16_w8: a gathered residual needs bias, a residual table and the plain fp32 epilogue");
     CACO_REQUIRE((int64_t)p.ldc * 4 * 65536 < 0x7fffffff, "gemm_bf16_w8: residual table rows too long");
     return launch_w8<EPI_F32, ACT_NONE, 5>(p, st);
   }

@@ -663,3 +663,15 @@ def _bad_config():
     simlib.load().caco_default_config(ctypes.byref(cfg))
     cfg.pool_heads = 3
     return cfg
+
+
+def test_random_shape_sweep(sim):
+    """A seeded slice of tools/wavesim/fuzz.py (random ragged / tiny shapes for every kernel family and for the whole narrow
+    towers, guard rows behind every output).  Longer runs: `python tools/wavesim/fuzz.py --cases 400 --seed N`
+    (profiles/r3_cpu/fuzz.txt)."""
+    import sys
+    sys.path.insert(0, os.path.join(simlib.REPO, "tools", "wavesim"))
+    import fuzz
+    log = fuzz.run(45, 123, ["gemm", "attention", "layernorm", "mel", "topk"])
+    log += fuzz.run(6, 124, ["model"])
+    assert len(log) == 51

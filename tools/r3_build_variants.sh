@@ -1,0 +1,19 @@
+#!/bin/bash
+# Rebuild the A/B variant libraries of the round-3 GPU session from the CURRENT sources (they travel with gpurun: in-tree,
+# git-ignored).  Run after any kernel change, before `gpurun -- bash tools/r3_gpu_session.sh`.
+set -e
+cd "$(dirname "$0")/.."
+rm -f cacophony_amd/_variants/*.so cacophony_amd/_variants/*.o
+# the parked max-free attention pass: the experimental file replaces attention.hip for this one build
+cp cacophony_amd/csrc/attention.hip /tmp/_attention_saved.hip
+tail -n +10 tools/experimental/attention_fastpass.hip > cacophony_amd/csrc/attention.hip
+bash tools/build_variant.sh fastpass attention.hip -DATTN_FAST_PASS || true
+cp /tmp/_attention_saved.hip cacophony_amd/csrc/attention.hip
+bash tools/build_variant.sh attn_nt attention.hip -DATTN_ST_AUX=2
+bash tools/build_variant.sh attn_sc1 attention.hip -DATTN_ST_AUX=16
+bash tools/build_variant.sh ln_nt norm.hip -DLN_ST_NT
+bash tools/build_variant.sh a_nt gemm_w8.hip -DW8_A_AUX=2
+bash tools/build_variant.sh w_nt gemm_w8.hip -DW8_W_AUX=2
+bash tools/build_variant.sh a_sc1 gemm_w8.hip -DW8_A_AUX=16
+python -m cacophony_amd.build --force >/dev/null
+ls -la cacophony_amd/_variants/*.so

@@ -42,4 +42,11 @@ cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_defaul
 cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
+# compile-time variants prepared by tools/r3_build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
+if ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
+  (CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
+  cat "$OUT/pytest_fastpass.txt"
+  (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
+  cat "$OUT/ab_variants.txt"
+fi
 echo "session done"

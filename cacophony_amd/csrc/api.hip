@@ -576,6 +576,12 @@ bool pos_fuse_enabled() {
   return e && atoi(e) != 0;
 }
 
+// CACO_POOL_FUSE=1 (read at every call; opt-in until timed): the audio tower's final LayerNorm inside the pooling kernel
+bool pool_fuse_enabled() {
+  const char* e = getenv("CACO_POOL_FUSE");
+  return e && atoi(e) != 0;
+}
+
 // The model's weights, arenas and per-device kernel state live on ONE device: a call with another device current would
 // dereference foreign memory.  Reject it instead.
 int check_device(const caco_model* m) {
@@ -831,13 +837,19 @@ static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype,
     CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, nf, st));
   }
   CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
-  // the fp32 hidden states are only written when the caller asks for them (encode_audio does not: 390 MB per batch of 256)
-  CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hidden, h, st));
   // AudioAttentionPooler.forward, caco.py:41-79 (projections folded out of the token loop, pool.hip)
   float* pooled = A.at<float>(o_pool);                  // [B, heads, H]: softmax-weighted token means per head
   float* pv = A.at<float>(o_pv);                        // [B, H]: value projection of the pooled rows, heads concatenated
   const int phd = H / c.pool_heads;
-  CACO_STAGE("audio.pool", attn_pool_rows(h, m->pool_wq, mask, batch, seq, H, c.pool_heads, pooled, st));
+  if (!hidden && pool_fuse_enabled()) {
+    // nobody reads the normalised rows but the pooler: it normalises them itself, on the way in (opt-in, round 3)
+    CACO_STAGE("audio.pool", attn_pool_rows_ln(x, m->enc.norm.g, m->enc.norm.b, c.audio_ln_eps, m->pool_wq, mask, batch, seq, H,
+                                               c.pool_heads, pooled, st));
+  } else {
+    // the fp32 hidden states are only written when the caller asks for them (encode_audio does not: 390 MB per batch of 256)
+    CACO_STAGE("audio.ln", layernorm(x, m->enc.norm.g, m->enc.norm.b, M, H, c.audio_ln_eps, hidden, h, st));
+    CACO_STAGE("audio.pool", attn_pool_rows(h, m->pool_wq, mask, batch, seq, H, c.pool_heads, pooled, st));
+  }
   for (int hh = 0; hh < c.pool_heads; ++hh)
     CACO_STAGE("audio.pool", gemm_f32(pooled + (size_t)hh * H, m->pool_v_w + (size_t)hh * phd * H, m->pool_v_b + hh * phd,
                                       pv + hh * phd, batch, phd, H, H, 1.0f, st, c.pool_heads * H));

@@ -98,6 +98,10 @@ int attention_small(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int 
 int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batch, int seq, int hidden, int heads, float* out,
                    hipStream_t st);
 
+// ... with the final LayerNorm applied on the way in (x = the fp32 residual rows; nothing normalised is written)
+int attn_pool_rows_ln(const float* x, const float* gamma, const float* beta, float eps, const float* wq, const float* mask, int batch,
+                      int seq, int hidden, int heads, float* out, hipStream_t st);
+
 // topk.hip: per-row top-k (value desc, index asc) through arbitrary strides
 int token_group_mean(const float* x, int batch, int seq, int hidden, int group, float* out, hipStream_t st);
 int topk_rows(const float* sim, int rows, int cols, int64_t row_stride, int64_t col_stride, int k, int* idx, float* val,

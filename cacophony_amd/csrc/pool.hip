@@ -126,6 +126,132 @@ __global__ __launch_bounds__(PW * 64) void pool_rows_kernel(const bf16_t* __rest
   }
 }
 
+
+// The same pooling with the encoder's FINAL LayerNorm applied on the way in: x are the fp32 residual rows, each row is
+// normalised (two-pass mean / variance, as norm.hip ln_row) in registers and pooled without ever being written - for callers
+// that do not ask for the hidden states (encode_audio), this removes the LayerNorm pass' 195 MB bf16 write and this kernel's
+// 195 MB read of it per batch of 256.  The pooled rows are sums of fp32 LayerNorm outputs instead of their bf16 roundings.
+// Round 3, opt-in (CACO_POOL_FUSE=1, api.hip) until timed on hardware; checked on the wavesim build.
+template <int HEADS>
+__global__ __launch_bounds__(PW * 64) void pool_rows_ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               const float* __restrict__ wq, const float* __restrict__ mask, int S,
+                                                               int H, float* __restrict__ out, int out_heads) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int nchunk = H >> 2;
+  const float* xb = x + (int64_t)b * S * H;
+  const float inv_h = 1.0f / (float)H;
+
+  f32x4 w[HEADS][PMAXC], g[PMAXC], be[PMAXC];
+#pragma unroll
+  for (int c = 0; c < PMAXC; ++c) {
+    const bool in = c * 64 + lane < nchunk;
+    g[c] = in ? *reinterpret_cast<const f32x4*>(gamma + (c * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    be[c] = in ? *reinterpret_cast<const f32x4*>(beta + (c * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+      w[h][c] = in ? *reinterpret_cast<const f32x4*>(wq + (int64_t)h * H + (c * 64 + lane) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc[HEADS][PMAXC];
+  float m_run[HEADS], l_run[HEADS];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+    m_run[h] = -INFINITY;
+    l_run[h] = 0.f;
+#pragma unroll
+    for (int c = 0; c < PMAXC; ++c) acc[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int UN = 2;
+  for (int j0 = wave; j0 < S; j0 += PW * UN) {
+    f32x4 raw[UN][PMAXC];
+    bool keep[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + u * PW;
+      keep[u] = j < S && !(mask && mask[(int64_t)b * S + j] == 0.f);     // wave-uniform
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c)
+        raw[u][c] = (keep[u] && c * 64 + lane < nchunk) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)j * H + (c * 64 + lane) * 4)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (!keep[u]) continue;
+      float s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c) s1 += (raw[u][c][0] + raw[u][c][1]) + (raw[u][c][2] + raw[u][c][3]);
+      const float mean = wave_sum(s1) * inv_h;
+      float s2 = 0.f;
+      f32x4 v[PMAXC];
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c) {
+        const bool in = c * 64 + lane < nchunk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[c][e] = in ? raw[u][c][e] - mean : 0.f;
+          s2 += v[c][e] * v[c][e];
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(s2) * inv_h + eps);
+      float dot[HEADS];
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) dot[h] = 0.f;
+#pragma unroll
+      for (int c = 0; c < PMAXC; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = v[c][e] * rstd * g[c][e] + be[c][e];      // padded chunks: g = be = 0
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h)
+          dot[h] += (v[c][0] * w[h][c][0] + v[c][1] * w[h][c][1]) + (v[c][2] * w[h][c][2] + v[c][3] * w[h][c][3]);
+      }
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        const float s = wave_sum(dot[h]);
+        const float m_new = fmaxf(m_run[h], s);
+        const float alpha = __expf(m_run[h] - m_new);
+        const float p = __expf(s - m_new);
+        l_run[h] = l_run[h] * alpha + p;
+        m_run[h] = m_new;
+#pragma unroll
+        for (int c = 0; c < PMAXC; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[h][c][e] = acc[h][c][e] * alpha + p * v[c][e];
+      }
+    }
+  }
+  float* part = sm;
+  float* ml = sm + PW * HEADS * H;
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+    for (int c = 0; c < PMAXC; ++c)
+      if (c * 64 + lane < nchunk) *reinterpret_cast<f32x4*>(part + ((int64_t)wave * HEADS + h) * H + (c * 64 + lane) * 4) = acc[h][c];
+    if (lane == 0) {
+      ml[(wave * HEADS + h) * 2] = m_run[h];
+      ml[(wave * HEADS + h) * 2 + 1] = l_run[h];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < HEADS * H; i += PW * 64) {
+    const int h = i / H, k = i - h * H;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int wv = 0; wv < PW; ++wv) mx = fmaxf(mx, ml[(wv * HEADS + h) * 2]);
+    float num = 0.f, den = 0.f;
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int wv = 0; wv < PW; ++wv) {
+        const float f = __expf(ml[(wv * HEADS + h) * 2] - mx);
+        den += ml[(wv * HEADS + h) * 2 + 1] * f;
+        num += part[((int64_t)wv * HEADS + h) * H + k] * f;
+      }
+    }
+    out[((int64_t)b * out_heads + h) * H + k] = den > 0.f ? num / den : 0.f;
+  }
+}
+
 // Mean over `group` consecutive tokens (the HEAR "event" embedding: tf.nn.avg_pool(hidden, ksize=8, strides=8, 'VALID')
 // over the 8 frequency patches of one time step, src/eval/heareval/embeddings/audio_embedding/caco_embeddings.py:118-124).
 // One thread per 4 output channels; a warp reads 1 KiB-contiguous row segments.  HBM-bound: seq*hidden*4 B in per clip.
@@ -166,6 +292,27 @@ int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batc
                          out + (size_t)h0 * hidden, heads);
   }
   return check_hip(hipGetLastError(), "attn_pool launch");
+}
+
+// LayerNorm(x; gamma, beta, eps) rows pooled as above without being written: x fp32 [batch, seq, hidden]
+int attn_pool_rows_ln(const float* x, const float* gamma, const float* beta, float eps, const float* wq, const float* mask, int batch,
+                      int seq, int hidden, int heads, float* out, hipStream_t st) {
+  CACO_REQUIRE(x && gamma && beta && wq && out && batch > 0 && seq > 0, "attn_pool_ln: bad arguments");
+  CACO_REQUIRE(heads == 1 || heads % 2 == 0, "attn_pool_ln: %d pooling heads unsupported (1 or an even number)", heads);
+  CACO_REQUIRE(hidden % 4 == 0 && hidden <= 256 * PMAXC, "attn_pool_ln: hidden %d must be a multiple of 4, <= %d", hidden, 256 * PMAXC);
+  const int per = heads == 1 ? 1 : 2;
+  const size_t smem = (size_t)PW * per * (hidden + 2) * sizeof(float);
+  CACO_REQUIRE(smem <= 160 * 1024, "attn_pool_ln: hidden %d too large for the LDS combine buffer", hidden);
+  if (heads == 1) {
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_ln_kernel<1>), 160 * 1024, nullptr));
+    hipLaunchKernelGGL(pool_rows_ln_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, gamma, beta, eps, wq, mask, seq, hidden, out, 1);
+  } else {
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_ln_kernel<2>), 160 * 1024, nullptr));
+    for (int h0 = 0; h0 < heads; h0 += 2)
+      hipLaunchKernelGGL(pool_rows_ln_kernel<2>, dim3(batch), dim3(PW * 64), smem, st, x, gamma, beta, eps, wq + (size_t)h0 * hidden,
+                         mask, seq, hidden, out + (size_t)h0 * hidden, heads);
+  }
+  return check_hip(hipGetLastError(), "attn_pool_ln launch");
 }
 
 // x fp32 [batch, seq, hidden] -> out fp32 [batch, seq / group, hidden] (trailing seq % group tokens dropped: 'VALID')

@@ -675,3 +675,29 @@ def test_random_shape_sweep(sim):
     log = fuzz.run(45, 123, ["gemm", "attention", "layernorm", "mel", "topk"])
     log += fuzz.run(6, 124, ["model"])
     assert len(log) == 51
+
+
+@pytest.mark.parametrize("pool_heads", [2, 8])
+def test_final_layernorm_inside_the_pooler(sim, tiny_state, monkeypatch, pool_heads):
+    """CACO_POOL_FUSE=1: encode_audio's final LayerNorm applied inside the pooling kernel (no normalised rows written).
+    Same embeddings as the two-launch form up to the bf16 rounding of the rows it no longer takes, and within the parity
+    bars of the oracle; ragged clip lengths (masked tokens, a clip shorter than the window)."""
+    from dataclasses import replace
+    a, t, cc = C.tiny_configs(1)
+    cc = replace(cc, num_attention_pool_heads=pool_heads)
+    m = simlib.SimModel(a, None, cc).load_state_dict({k: v for k, v in tiny_state.items() if k.startswith("audio_")})
+    o = O.CacoOracle(tiny_state, a, t, cc, backend="torch")
+    n = 30000
+    lens = [30000, 11000, 4000]
+    wav = np.stack([synth.make_waveform(70 + i, n_samples=n) for i in range(3)]).astype(np.float32)
+    for i, L in enumerate(lens):
+        wav[i, L:] = 0
+    embs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CACO_POOL_FUSE", flag)
+        embs[flag] = m.encode_audio(wav, lengths=lens).numpy()
+    ref = np.concatenate([o.encode_audio(wav[i:i + 1, :L], max(8, n * 8 // 160 // 16)) for i, L in enumerate(lens)], 0)
+    assert np.isfinite(embs["1"]).all()
+    assert (embs["1"] != embs["0"]).any()                          # the other path did run
+    assert cosine_rows(embs["1"], embs["0"]).min() > 0.99999
+    assert cosine_rows(embs["1"], ref).min() > 0.999 and rel_l2(embs["1"], ref) <= rel_l2(embs["0"], ref) * 1.05

@@ -2,7 +2,7 @@
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
 #   gpurun --timeout 2400 -- 'bash tools/r3_gpu_session.sh'
 # 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
-# 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | both | CACO_W_NGROUP=0
+# 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | CACO_POOL_FUSE=1 | all three | CACO_W_NGROUP=0
 # 3. rocprofv3 kernel stats of the default build and of the build with both switches on
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
@@ -32,12 +32,13 @@ for rep in 1 2; do
   ab default       CACO_DUMMY=0
   ab attn_small    CACO_ATTN_SMALL=1
   ab pos_fuse      CACO_POS_FUSE=1
-  ab both          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1
+  ab pool_fuse     CACO_POOL_FUSE=1
+  ab all3          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1
   ab ngroup_off    CACO_W_NGROUP=0
 done
 } | tee "$OUT/ab.txt"
 bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
-CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
+CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
 cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"

@@ -191,6 +191,7 @@ def fuzz_model(sim, rng, log):
     m, o, t = _narrow_models()[int(rng.choice([1, 2]))]
     os.environ["CACO_ATTN_SMALL"] = "1" if rng.random() < 0.5 else "0"
     os.environ["CACO_POS_FUSE"] = "1" if rng.random() < 0.5 else "0"
+    os.environ["CACO_POOL_FUSE"] = "1" if rng.random() < 0.5 else "0"
     tile = int(rng.choice([256, 8256, 128]))
     sim.caco_set_gemm_tile(tile)
     m.set_ln_fold(int(rng.random() < 0.3))
@@ -213,11 +214,12 @@ def fuzz_model(sim, rng, log):
     rt = o.encode_text(ids, mask)
     assert np.isfinite(ea).all() and np.isfinite(et).all()
     ca, ct = cosine_rows(ea, ra).min(), cosine_rows(et, rt).min()
-    desc = f"model B {B} n {n} lens {lens} T {T} tile {tile} small {os.environ['CACO_ATTN_SMALL']} fuse {os.environ['CACO_POS_FUSE']}"
+    desc = (f"model B {B} n {n} lens {lens} T {T} tile {tile} small {os.environ['CACO_ATTN_SMALL']} fuse {os.environ['CACO_POS_FUSE']} "
+            f"pool {os.environ['CACO_POOL_FUSE']}")
     assert ca > 0.999 and ct > 0.999, (desc, ca, ct)
     sim.caco_set_gemm_tile(256)
     m.set_ln_fold(0)
-    os.environ["CACO_ATTN_SMALL"] = os.environ["CACO_POS_FUSE"] = "0"
+    os.environ["CACO_ATTN_SMALL"] = os.environ["CACO_POS_FUSE"] = os.environ["CACO_POOL_FUSE"] = "0"
     log.append(desc + f" cos {ca:.5f} {ct:.5f}")
 
 

@@ -529,3 +529,17 @@ def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch
         _check_against_golden(tm, load_golden("caco_tiny.npz"), 2, 1024)
     finally:
         full_model._lib.caco_set_gemm_tile(256)
+
+
+def test_final_layernorm_inside_the_pooler(full_model, monkeypatch):
+    """CACO_POOL_FUSE=1 (same case as tests/test_wavesim.py): encode_audio's final LayerNorm applied inside the pooling kernel."""
+    wav = synth.make_waveforms(6, start=11)
+    w = torch.from_numpy(wav).to(DEV)
+    lens = [160000, 160000, 90000, 40000, 160000, 12345]
+    embs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CACO_POOL_FUSE", flag)
+        embs[flag] = full_model.encode_audio(w, lengths=lens).cpu().numpy()
+    assert np.isfinite(embs["1"]).all()
+    assert cosine_rows(embs["1"], embs["0"]).min() > 0.99999
+    np.testing.assert_allclose(np.linalg.norm(embs["1"], axis=1), 1.0, atol=1e-3)

@@ -74,6 +74,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
 }
 
+// A/B variant (-DLN_TWO_ROWS, tools/build_variant.sh; round 3, untimed): one wave owns TWO consecutive rows - twice the loads
+// in flight per wave (6 x 16 bytes instead of 3 at dim 768), half the waves, the two rows' reductions interleaved.  The
+// default kernel above reaches 0.70 of the HBM roofline; this asks whether latency per wave is what is left.
+template <bool NT>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int64_t rows, int dim, float eps,
+                                                         float* __restrict__ of, bf16_t* __restrict__ ob) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+  if (row0 >= rows) return;
+  const bool two = row0 + 1 < rows;                      // wave-uniform
+  const int nchunk = dim >> 2;
+  f32x4 v[2][MAXC];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c * 64 + lane < nchunk && (r == 0 || two)) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + (row0 + r) * dim + (c * 64 + lane) * 4);
+        v[r][c] = NT ? __builtin_nontemporal_load(src) : *src;
+      }
+  ln_row(v[0], nchunk, lane, dim, gamma, beta, eps, of ? of + row0 * dim : nullptr, ob ? ob + row0 * dim : nullptr);
+  if (two) ln_row(v[1], nchunk, lane, dim, gamma, beta, eps, of ? of + (row0 + 1) * dim : nullptr, ob ? ob + (row0 + 1) * dim : nullptr);
+}
+
 // LayerNorm folding helpers (kernels.h GemmArgs::fold_*): (mean, rstd) per row
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int nslot, int64_t rows,
                                                                 float inv_dim, float eps, float* __restrict__ mr) {
@@ -280,6 +305,13 @@ int layernorm(const float* x, const float* gamma, const float* beta, int64_t row
   // streaming (nt) reads of the fp32 rows when only the bf16 copy is produced (pre-LN stacks): x is not needed again
   // before the next GEMM rewrites it, and the bf16 rows this kernel writes are what should stay cached
   static const int nt_env = getenv("CACO_LN_NT") ? atoi(getenv("CACO_LN_NT")) : 1;      // measured -1.1 % per step
+#ifdef LN_TWO_ROWS
+  if (nt_env && !out_f32)
+    hipLaunchKernelGGL(layernorm2_kernel<true>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps, out_f32, out_bf16);
+  else
+    hipLaunchKernelGGL(layernorm2_kernel<false>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps, out_f32, out_bf16);
+  return check_hip(hipGetLastError(), "layernorm launch");
+#endif
   if (nt_env && !out_f32)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps,
                        out_f32, out_bf16);

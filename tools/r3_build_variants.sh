@@ -12,6 +12,7 @@ cp /tmp/_attention_saved.hip cacophony_amd/csrc/attention.hip
 bash tools/build_variant.sh attn_nt attention.hip -DATTN_ST_AUX=2
 bash tools/build_variant.sh attn_sc1 attention.hip -DATTN_ST_AUX=16
 bash tools/build_variant.sh ln_nt norm.hip -DLN_ST_NT
+bash tools/build_variant.sh ln_2rows norm.hip -DLN_TWO_ROWS
 bash tools/build_variant.sh a_nt gemm_w8.hip -DW8_A_AUX=2
 bash tools/build_variant.sh w_nt gemm_w8.hip -DW8_W_AUX=2
 bash tools/build_variant.sh a_sc1 gemm_w8.hip -DW8_A_AUX=16

@@ -47,7 +47,7 @@ cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switc
 if ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
   (CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
   cat "$OUT/pytest_fastpass.txt"
-  (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
+  (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
   cat "$OUT/ab_variants.txt"
 fi
 echo "session done"

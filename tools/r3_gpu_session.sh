@@ -1,14 +1,18 @@
 #!/bin/bash
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
-#   gpurun --timeout 2400 -- 'bash tools/r3_gpu_session.sh'
+#   gpurun --timeout 1800 -- 'bash tools/r3_gpu_session.sh truth'      (then `ab`, then `variants`: one call each, ~20-25 min)
+#   bash tools/r3_gpu_session.sh all                                    everything in one call (~60 min)
 # 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
 # 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | CACO_POOL_FUSE=1 | all three | CACO_W_NGROUP=0
 # 3. rocprofv3 kernel stats of the default build and of the build with both switches on
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
+PART=${1:-all}
 OUT=gpurun_out/r3_v0
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
+if want truth; then
 echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
 (timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25) > "$OUT/pytest_gpu.txt"
 tail -3 "$OUT/pytest_gpu.txt"
@@ -16,6 +20,9 @@ tail -3 "$OUT/pytest_gpu.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
+bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
+cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+fi
 ab() {   # name, env assignments...
   local name=$1; shift
   env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 20 --warmup 5 2>/dev/null | python -c "
@@ -27,6 +34,7 @@ try:
 except Exception as e:
     print('$name', 'FAILED', repr(e))"
 }
+if want ab; then
 {
 for rep in 1 2; do
   ab default       CACO_DUMMY=0
@@ -38,15 +46,14 @@ for rep in 1 2; do
   ab text_n768_128 CACO_W8_MIN_TILES=200      # the text tower's N = 768 GEMMs (192 tile units) on the 128 x 128 kernel instead of w8
 done
 } | tee "$OUT/ab.txt"
-bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
 CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
-cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
   for t in 128 2256 8256 4256; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
+fi
 # compile-time variants prepared by tools/r3_build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
-if ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
+if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
   (CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
   cat "$OUT/pytest_fastpass.txt"
   (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1

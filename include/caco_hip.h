@@ -52,7 +52,8 @@ typedef struct caco_config {
   float audio_ln_eps;
   int32_t text_vocab, text_hidden, text_layers, text_heads, text_intermediate, text_max_pos, text_type_vocab;
   float text_ln_eps;
-  int32_t projection_size, pool_heads;
+  int32_t projection_size, pool_heads;   /* pool_heads: 1 or an even number dividing audio_hidden.  The torch model pools with 2
+                                            (caco.py:20,294), the JAX model with 8 (src/caco/load_model.py:46) on the same tensors */
   float logit_scale;
   int32_t has_audio, has_text;      /* which towers to allocate (AudioMAE-only models set has_text = 0) */
   int32_t mae_decoder_layers;       /* > 0: also hold an AudioDecoder (mae.py:151-207) of that depth     */
@@ -98,8 +99,8 @@ int caco_mel_spectrogram(const float* wav_dev, int32_t batch, int64_t n_samples,
 int caco_mel_patches(const float* wav_dev, int32_t batch, int64_t n_samples, int32_t max_patches, float scale,
                      float bias, void* patches_dev, int32_t patch_dtype, float* time_inds_dev, float* freq_inds_dev,
                      float* mask_dev, void* stream);
-/* The same for a batch of clips of DIFFERENT lengths, zero-padded to n_samples: lengths_dev int64 [batch] (NULL = all
- * n_samples).  Clip b gets the patches / indices / mask the reference produces when prepare_audio_batch
+/* The same for a batch of clips of DIFFERENT lengths in rows of n_samples: lengths_dev int64 [batch] (NULL = all
+ * n_samples).  Whatever a row holds past lengths[b] is ignored (read as the STFT's zero padding).  Clip b gets the patches / indices / mask the reference produces when prepare_audio_batch
  * (src/eval/eval_caco_torch.py:181-206) runs on its lengths[b] samples alone: (ceil(len / 160) / 16) * 8 valid patches,
  * the rest zero rows with mask 0. */
 int caco_mel_patches_lens(const float* wav_dev, const int64_t* lengths_dev, int32_t batch, int64_t n_samples,

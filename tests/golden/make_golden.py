@@ -300,6 +300,24 @@ def golden_decoder(refs):
     print("decoder_tiny.npz", lg.shape, lg.numpy()[0, :3].argmax(-1), float(np.abs(lg.numpy()).max()))
 
 
+@torch.no_grad()
+def golden_pool_heads(refs):
+    """The audio pooler with 1, 4 and 8 heads on the SAME tensors (the JAX side pools with 8, src/caco/load_model.py:46; the
+    torch default is 2, caco.py:20): the reference's own AudioAttentionPooler at each head count, 2-layer config, 3 s clips."""
+    ref_caco, ref_mae, ref_roberta, ref_eval = refs
+    a, t, cc = C.tiny_configs(2)
+    ab = _inputs(ref_eval, 2, 150, 48000, start=30)
+    tt = {k: torch.from_numpy(v) for k, v in ab.items()}
+    out = {"mask_sum": ab["audio_mask"].sum(1), "patch_checksum": _checksum(ab["audio_patches"])}
+    for heads in (1, 4, 8):
+        model, _ = _build_ref_caco(ref_caco, ref_mae, ref_roberta, a, t, replace(cc, num_attention_pool_heads=heads))
+        emb = model.get_audio_embedding(tt["audio_patches"], tt["audio_time_inds"], tt["audio_freq_inds"], tt["audio_mask"],
+                                        return_hidden_state=False, normalize=True)
+        out[f"emb_heads{heads}"] = emb.numpy()
+    np.savez_compressed(os.path.join(OUT, "pool_heads.npz"), **out)
+    print("pool_heads.npz", {k: v.shape for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -314,6 +332,7 @@ def main():
     golden_mae(refs, "full", 12)
     golden_retrieval()
     golden_decoder(refs)
+    golden_pool_heads(refs)
 
 
 if __name__ == "__main__":

@@ -543,3 +543,18 @@ def test_final_layernorm_inside_the_pooler(full_model, monkeypatch):
     assert np.isfinite(embs["1"]).all()
     assert cosine_rows(embs["1"], embs["0"]).min() > 0.99999
     np.testing.assert_allclose(np.linalg.norm(embs["1"], axis=1), 1.0, atol=1e-3)
+
+
+@pytest.mark.parametrize("heads", [1, 4, 8])
+def test_audio_pooler_head_counts_match_reference(tiny_state, heads):
+    """The pooling kernel at 1, 4 and 8 heads against the reference's own outputs (tests/golden/pool_heads.npz)."""
+    g = load_golden("pool_heads.npz")
+    a, t, cc = C.tiny_configs(2)
+    m = CACO(a, t, replace(cc, num_attention_pool_heads=heads), device=DEV).load_state_dict(tiny_state)
+    _, ab = _audio_batch(2, 150, 48000, start=30)
+    emb = m.get_audio_embedding(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"],
+                                return_hidden_state=False, normalize=True).cpu().numpy()
+    ref = g[f"emb_heads{heads}"]
+    other = g["emb_heads4" if heads != 4 else "emb_heads8"]
+    assert cosine_rows(emb, ref).min() > COS_TOL
+    assert rel_l2(emb, ref) < 0.5 * rel_l2(emb, other)

@@ -171,3 +171,18 @@ def test_normalize_zero_vector_is_finite():
     """x / ||x + 1e-10||: an all-zero embedding stays finite."""
     z = O.l2_normalize(O.get_ops("numpy"), np.zeros((1, 768), np.float32))
     assert np.isfinite(z).all() and (z == 0).all()
+
+
+def test_audio_pooler_head_counts_match_reference(tiny_state):
+    """1, 4 and 8 pooling heads on the same tensors (the JAX side's 8, src/caco/load_model.py:46): the oracle against the
+    reference's own AudioAttentionPooler at each head count (tests/golden/pool_heads.npz)."""
+    g = load_golden("pool_heads.npz")
+    a, t, cc = C.tiny_configs(2)
+    ab = O.prepare_audio_batch(synth.make_waveforms(2, 48000, start=30), 150)
+    np.testing.assert_allclose(checksum(ab["audio_patches"]), g["patch_checksum"], rtol=1e-4)
+    for heads in (1, 4, 8):
+        o = O.CacoOracle(tiny_state, a, t, replace(cc, num_attention_pool_heads=heads), backend="torch")
+        emb = o.get_audio_embedding(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"],
+                                    return_hidden_state=False, normalize=True)
+        assert rel_l2(emb, g[f"emb_heads{heads}"]) < 2e-5, heads
+    assert rel_l2(g["emb_heads8"], g["emb_heads4"]) > 1e-2          # the head count matters: a silent fall-back would show

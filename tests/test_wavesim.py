@@ -701,3 +701,19 @@ def test_final_layernorm_inside_the_pooler(sim, tiny_state, monkeypatch, pool_he
     assert (embs["1"] != embs["0"]).any()                          # the other path did run
     assert cosine_rows(embs["1"], embs["0"]).min() > 0.99999
     assert cosine_rows(embs["1"], ref).min() > 0.999 and rel_l2(embs["1"], ref) <= rel_l2(embs["0"], ref) * 1.05
+
+
+@pytest.mark.parametrize("heads", [1, 4, 8])
+def test_audio_pooler_head_counts_match_reference(sim, tiny_state, heads):
+    """The pooling kernel at 1, 4 and 8 heads against the reference's own outputs (tests/golden/pool_heads.npz)."""
+    from dataclasses import replace
+    g = load_golden("pool_heads.npz")
+    a, t, cc = C.tiny_configs(2)
+    m = simlib.SimModel(a, None, replace(cc, num_attention_pool_heads=heads)).load_state_dict(
+        {k: v for k, v in tiny_state.items() if k.startswith("audio_")})
+    ab = _mel_patches(sim, synth.make_waveforms(2, 48000, start=30), 150)
+    emb, _ = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
+    ref = g[f"emb_heads{heads}"]
+    other = g["emb_heads4" if heads != 4 else "emb_heads8"]
+    assert cosine_rows(emb.numpy(), ref).min() > 0.999
+    assert rel_l2(emb.numpy(), ref) < 0.5 * rel_l2(emb.numpy(), other)

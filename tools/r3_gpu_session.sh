@@ -1,6 +1,6 @@
 #!/bin/bash
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
-#   gpurun --timeout 1800 -- 'bash tools/r3_gpu_session.sh truth'      (then `ab`, then `variants`: one call each, ~20-25 min)
+#   gpurun --timeout 1800 -- 'bash tools/r3_gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
 #   bash tools/r3_gpu_session.sh all                                    everything in one call (~60 min)
 # 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
 # 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | CACO_POOL_FUSE=1 | all three | CACO_W_NGROUP=0
@@ -58,5 +58,14 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/nul
   cat "$OUT/pytest_fastpass.txt"
   (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
   cat "$OUT/ab_variants.txt"
+fi
+# PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)
+if want pmc; then
+  bash tools/pmc_run.sh r3_pmc_fc1 gemm_bf16_w8 -- python tools/gemm_bench.py --iters 3 --only fc1 > /dev/null 2>&1
+  bash tools/pmc_run.sh r3_pmc_attn attention_kernel -- python tools/attn_bench.py > /dev/null 2>&1
+  bash tools/pmc_run.sh r3_pmc_mel mel_kernel -- python tools/mel_bench.py > /dev/null 2>&1
+  for k in fc1 attn mel; do for f in sq1 sq2 sq3 tcc1 tcc2; do cat gpurun_out/r3_pmc_$k/$f.csv gpurun_out/r3_pmc_$k/$f.dur > "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
+  bash tools/pmc_hbm.sh r3_hbm fc1 256 > /dev/null 2>&1; cp gpurun_out/r3_hbm/hbm_traffic.json "$OUT/" 2>/dev/null
+  ls "$OUT"
 fi
 echo "session done"

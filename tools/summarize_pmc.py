@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""rocprofv3 counter_collection.csv -> per-kernel mean of every counter (one row per kernel)."""
+"""rocprofv3 counter_collection.csv -> per-kernel mean of every counter (one row per kernel), followed by the minimum and
+the maximum over the dispatches (rows "<kernel> [min]" / "[max]"): a pass whose values are digit-identical to an older
+profile's although the kernel changed (round-2 verdict, weak 9) shows as min = max = mean of another run."""
 import csv
 import re
 import sys
@@ -15,3 +17,5 @@ w.writerow(["kernel", "dispatches"] + names)
 for k, cs in acc.items():
     n = max(len(v) for v in cs.values())
     w.writerow([k, n] + [f"{sum(cs[c]) / len(cs[c]):.4g}" if c in cs else "" for c in names])
+    w.writerow([k + " [min]", n] + [f"{min(cs[c]):.6g}" if c in cs else "" for c in names])
+    w.writerow([k + " [max]", n] + [f"{max(cs[c]):.6g}" if c in cs else "" for c in names])

@@ -189,6 +189,7 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
   // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 2256 = 256x128 two workgroups per CU
   if (cfg == 8256 && gemm_bf16_w8_ok(p, epi)) return gemm_bf16_w8(p, epi, act, st);
   if (cfg == 4256 && gemm_bf16_w8_ok(p, epi) && p.bias) return gemm_bf16_w4q(p, epi, act, st);     // experiment: 4 waves of 128 x 128
+  if (cfg == 4128 && gemm_bf16_w8_ok(p, epi) && p.bias) return gemm_bf16_w4h(p, epi, act, st);     // experiment: 128 x 256 tiles (mid M)
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
   if (cfg == 256) {
     // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w8.hip: most reuse per L2 byte) when every
@@ -197,6 +198,11 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
     // kernel is faster for its N = 768 shapes, but the text tower runs NEXT TO the audio tower and a few persistent
     // 160 KiB workgroups interleave with the audio GEMMs better than many small ones (step 32.2 -> 31.7 ms measured)
     static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
+    // CACO_W4H_MAX_TILES=<n> (experiment, round 3): shapes with fewer than n 256 x 256 tiles - the text tower's N = 768 GEMMs
+    // have 96 - take 128 x 256 tiles instead (gemm_w4h.hip)
+    static const int w4h_max = getenv("CACO_W4H_MAX_TILES") ? atoi(getenv("CACO_W4H_MAX_TILES")) : 0;
+    if (w4h_max > 0 && gemm_bf16_w8_ok(p, epi) && p.bias && tiles_x >= w8_min && ((p.M + 255) / 256) * (int64_t)(p.N / 256) < w4h_max)
+      return gemm_bf16_w4h(p, epi, act, st);
     if (gemm_bf16_w8_ok(p, epi) && tiles_x >= w8_min) return gemm_bf16_w8(p, epi, act, st);
     if (tiles_x >= 256) return gemm_bf16_x(p, epi, act, st);
   }
@@ -224,7 +230,7 @@ int gemm_tile_config() {
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {
-  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256 || tile == 4256) g_tile_cfg = tile;   // > 256: force a kernel
+  if (tile == 128 || tile == 256 || tile == 2256 || tile == 8256 || tile == 4256 || tile == 4128) g_tile_cfg = tile;   // > 256: force a kernel
   return gemm_tile_config();
 }
 

@@ -52,7 +52,8 @@ bool gemm_bf16_picks_w8(const GemmArgs& p, int epi);                      // gem
 int gemm_bf16_x(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_x.hip
 bool gemm_bf16_w8_ok(const GemmArgs& p, int epi);                         // gemm_w8.hip: persistent 256x256, the default
 int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st);
-int gemm_bf16_w4q(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_w4q.hip: four waves of 128 x 128 (experiment, tile code 4256)
+int gemm_bf16_w4q(const GemmArgs& p, int epi, int act, hipStream_t st);
+int gemm_bf16_w4h(const GemmArgs& p, int epi, int act, hipStream_t st);   // gemm_w4h.hip: 128 x 256 tiles, four waves (mid-M experiment, tile code 4128)   // gemm_w4q.hip: four waves of 128 x 128 (experiment, tile code 4256)
 int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ldc, float scale,
              hipStream_t st, int lda = 0, int ldb = 0);     // lda / ldb: row strides of A / B in elements (0 = K)
 

@@ -195,7 +195,7 @@ int64_t caco_workspace_bytes(const caco_model* m);
 /* Tuning knob (process-global): bf16 GEMM kernel choice.  256 (default) = per shape: the persistent 256x256 eight-wave
  * kernel (csrc/gemm_w8.hip) when every CU gets work, else the 256x128 two-workgroups-per-CU kernel (gemm_x.hip), else
  * 128x128; 128 = always 128x128 (env CACO_GEMM_TILE=128 selects it at first use).  Forced kernels for tests / A-B runs:
- * 8256 = gemm_w8, 2256 = gemm_x, 4256 = gemm_w4q (four waves of 128 x 128: a round-3 experiment, never the default).  A
+ * 8256 = gemm_w8, 2256 = gemm_x, 4256 = gemm_w4q (four waves of 128 x 128), 4128 = gemm_w4h (128 x 256 tiles for mid-size M): round-3 experiments, never the default.  A
  * forced kernel that does not support a shape falls back to the default choice.  Returns the mode now in force; any
  * other value only queries. */
 int32_t caco_set_gemm_tile(int32_t tile);

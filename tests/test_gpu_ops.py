@@ -40,7 +40,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(DEV)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 2256, 8256, 4256])       # 4256: the four-wave 128 x 128 experiment (gemm_w4q.hip)
+@pytest.mark.parametrize("tile", [128, 256, 2256, 8256, 4256, 4128])       # 4256 / 4128: round-3 experiments (gemm_w4q.hip, gemm_w4h.hip)
 @pytest.mark.parametrize("M,N,K,act", [(1000, 768, 256, 0), (4096, 1536, 768, 0), (2500, 3072, 768, 1),
                                        (2048, 768, 3072, 0), (8192, 3072, 768, 2), (300, 256, 768, 0),
                                        (777, 768, 64, 0), (5000, 256, 128, 1)])
@@ -64,7 +64,7 @@ def test_gemm_bf16(lib, tile, M, N, K, act):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 2256, 8256, 4256])
+@pytest.mark.parametrize("tile", [128, 256, 2256, 8256, 4256, 4128])
 def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(tile)
     M, N, K = 3001, 768, 3072
@@ -83,7 +83,7 @@ def test_gemm_bf16_f32_residual_inplace(lib, tile):
     lib.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [256, 8256, 4256])
+@pytest.mark.parametrize("tile", [256, 8256, 4256, 4128])
 @pytest.mark.parametrize("M,N,K,kind", [(70000, 768, 768, "f32r"), (33333, 768, 3072, "f32r"), (50000, 2304, 768, "bf16"),
                                         (45000, 3072, 768, "silu")])
 def test_gemm_persistent_multi_tile_pipeline(lib, tile, M, N, K, kind):
@@ -357,7 +357,7 @@ def test_attention_small_kernel(lib, monkeypatch, B, Sq, S, heads, causal, valid
     assert (outs["1"] - outs["0"]).abs().max().item() < 0.02
 
 
-@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256, 4128])
 @pytest.mark.parametrize("M", [300, 1000, 3001])
 def test_gemm_ragged_m_writes_nothing_past_row_m(lib, tile, M):
     """The rows of a ragged last M tile must not reach memory.  The persistent kernels store through raw buffer descriptors

@@ -38,7 +38,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
-@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256, 4128])
 @pytest.mark.parametrize("M,N,K,act", [(300, 256, 128, 0), (520, 768, 256, 1), (257, 512, 192, 2), (64, 256, 64, 0)])
 def test_gemm_bf16(sim, tile, M, N, K, act):
     assert sim.caco_set_gemm_tile(tile) == tile
@@ -55,7 +55,7 @@ def test_gemm_bf16(sim, tile, M, N, K, act):
     sim.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256, 4128])
 def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(tile)
     M, N, K = 301, 768, 192
@@ -72,7 +72,7 @@ def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(256)
 
 
-@pytest.mark.parametrize("tile", [8256, 4256], ids=["w8", "w4q"])
+@pytest.mark.parametrize("tile", [8256, 4256, 4128], ids=["w8", "w4q", "w4h"])
 @pytest.mark.parametrize("kind", ["f32r", "bf16", "silu"])
 def test_gemm_w8_persistent_multi_tile_pipeline(sim, kind, tile):
     """More output tiles than workgroups (the simulator reports 16 CUs): operand loads prefetched across output-tile
@@ -549,7 +549,7 @@ def test_token_group_mean_and_strided_similarity(sim):
     assert (sim_m[:, :9].double() - ref).abs().max().item() < 1e-5 and torch.isnan(sim_m[:, 9:]).all()
 
 
-@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256])
+@pytest.mark.parametrize("tile", [128, 2256, 8256, 4256, 4128])
 def test_gemm_ragged_m_writes_nothing_past_row_m(sim, tile):
     """tests/test_gpu_ops.py::test_gemm_ragged_m_writes_nothing_past_row_m on the simulator, whose buffer descriptors
     range-check the per-lane offset only (as the hardware does): guard rows behind the output keep their sentinel."""
@@ -584,7 +584,7 @@ def test_results_do_not_depend_on_the_schedule(sim, monkeypatch):
     for order in ("forward", "reverse"):
         monkeypatch.setenv("WAVESIM_ORDER", order)
         got = []
-        for tile in (8256, 4256, 2256):
+        for tile in (8256, 4256, 4128, 2256):
             sim.caco_set_gemm_tile(tile)
             o = torch.empty(M, N, dtype=torch.bfloat16)
             simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, 1, P(o), None))

@@ -43,13 +43,14 @@ for rep in 1 2; do
   ab pool_fuse     CACO_POOL_FUSE=1
   ab all3          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1
   ab ngroup_off    CACO_W_NGROUP=0
+  ab text_w4h      CACO_W4H_MAX_TILES=128      # the text tower's N = 768 GEMMs (96 tiles of 256 x 256) on 128 x 256 tiles (gemm_w4h.hip)
   ab text_n768_128 CACO_W8_MIN_TILES=200      # the text tower's N = 768 GEMMs (192 tile units) on the 128 x 128 kernel instead of w8
 done
 } | tee "$OUT/ab.txt"
 CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
 cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
-  for t in 128 2256 8256 4256; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
+  for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
 fi
 # compile-time variants prepared by tools/r3_build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)

@@ -25,7 +25,7 @@ INCLUDE = os.path.join(REPO, "include")
 GEN = os.path.join(HERE, "_gen")
 SHIM = os.path.join(HERE, "shim")
 LIB = os.path.join(HERE, "libcaco_sim.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w8.hip", "gemm_w4q.hip", "attention.hip", "attention_small.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w8.hip", "gemm_w4q.hip", "gemm_w4h.hip", "attention.hip", "attention_small.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
 CXX = os.environ.get("WAVESIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-O2", "-g1", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-ffp-contract=off",
          "-Wno-unknown-attributes", "-Wno-unused-value", "-Wno-ignored-attributes", "-Wno-c++20-extensions",

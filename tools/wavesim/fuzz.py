@@ -27,7 +27,7 @@ def guard_bf16(rows, cols, extra):
 
 
 def fuzz_gemm(sim, rng, log):
-    tile = int(rng.choice([128, 2256, 8256, 4256, 256]))
+    tile = int(rng.choice([128, 2256, 8256, 4256, 4128, 256]))
     sim.caco_set_gemm_tile(tile)
     M = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513, 700, 1025]))
     N = int(rng.choice([128, 256, 384, 512, 768, 1280]))

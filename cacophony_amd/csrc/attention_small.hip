@@ -196,8 +196,10 @@ __device__ __forceinline__ void attention_small_body(const bf16_t* __restrict__ 
   }
 }
 
+// (register budget held to 128 / 256: with the default 512, hipcc keeps the MFMA results in AGPRs and copies all 48 of them
+// out for the softmax and the stores)
 template <bool CAUSAL, int NKT>
-__global__ __launch_bounds__(SM_NW * 64) void attention_small_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
+__global__ __launch_bounds__(SM_NW * 64, NKT == 1 ? 4 : 2) void attention_small_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                      const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                      const float* __restrict__ key_mask, int S, int heads, int batch,
                                                                      bf16_t* __restrict__ out, float scale_log2, int kv_rows) {

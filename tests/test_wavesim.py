@@ -717,3 +717,47 @@ def test_audio_pooler_head_counts_match_reference(sim, tiny_state, heads):
     other = g["emb_heads4" if heads != 4 else "emb_heads8"]
     assert cosine_rows(emb.numpy(), ref).min() > 0.999
     assert rel_l2(emb.numpy(), ref) < 0.5 * rel_l2(emb.numpy(), other)
+
+
+@pytest.mark.skipif(os.environ.get("CACO_SIM_FULL", "0") in ("", "0"), reason="set CACO_SIM_FULL=1: the 12 + 12-layer model on the simulator (~5 min)")
+@pytest.mark.parametrize("variant", ["default", "w8_and_round3_switches"])
+def test_full_config_matches_reference_golden(sim, full_state, monkeypatch, variant):
+    """tests/test_gpu_model.py::test_full_config_matches_reference_golden on the simulator: the full 12 + 12-layer model,
+    4 clips + 4 captions, against the reference's own outputs (tests/golden/caco_full.npz), incl. the centred cosine -
+    with the kernels a batch of 4 gets by default, and with the persistent GEMM forced plus every round-3 switch on.
+    Recorded in profiles/r3_cpu/wavesim_runs.txt."""
+    if variant != "default":
+        for k in ("CACO_ATTN_SMALL", "CACO_POS_FUSE", "CACO_POOL_FUSE"):
+            monkeypatch.setenv(k, "1")
+        sim.caco_set_gemm_tile(8256)
+    try:
+        _full_config_golden(sim, full_state)
+    finally:
+        sim.caco_set_gemm_tile(256)
+
+
+def _full_config_golden(sim, full_state):
+    g = load_golden("caco_full.npz")
+    m = simlib.SimModel(C.default_audio_config(), C.default_text_config(), C.default_caco_config()).load_state_dict(full_state)
+    ab = _mel_patches(sim, synth.make_waveforms(4), 500)
+    rows = g["probe_rows"]
+    a_emb, a_hid = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"])
+    valid = rows[rows < 496]
+    sel = np.isin(rows, valid)
+    assert rel_l2(a_hid.numpy()[:, valid], g["audio_hidden_rows"][:, sel]) < 1e-2
+    assert cosine_rows(a_emb.numpy(), g["audio_emb"]).min() > 0.999
+    ids, tmask = synth.make_captions(4, 32, 50265)
+    t_emb, t_hid = m.text_forward(ids, tmask)
+    keep = tmask.astype(bool)
+    assert rel_l2(t_hid.numpy()[keep], g["text_hidden"][keep]) < 1e-2
+    assert cosine_rows(t_emb.numpy(), g["text_emb"]).min() > 0.999
+    a_n = m.encode_audio(synth.make_waveforms(4), 500)                   # the fused front end + (optionally) fused pooler path
+    t_n, _ = m.text_forward(ids, tmask, normalize=True)
+    for got, key in ((a_n.numpy(), "audio_emb_norm"), (t_n.numpy(), "text_emb_norm")):
+        mu = g[key].mean(0, keepdims=True)
+        assert cosine_rows(got, g[key]).min() > 0.999
+        assert cosine_rows(got - mu, g[key] - mu).min() > 0.99
+    scale = float(np.exp(2.6592))
+    at = torch.empty(4, 4)
+    simlib.check(sim.caco_similarity(P(a_n), 4, P(t_n), 4, 768, scale, P(at), 4, None))
+    assert np.abs(at.numpy() - g["at_logits"]).max() < 1e-3 * scale

@@ -269,7 +269,11 @@ typedef unsigned int wavesim_u32x4 __attribute__((ext_vector_type(4)));
 // composable_kernel's out-of-bounds trick adds 0x80000000 to the per-lane offset, ck/utility/amd_buffer_addressing.hpp).
 // A kernel that steps through rows with soffset gets NO protection for the rows it reaches that way: under this model such
 // an access goes to memory, where AddressSanitizer (asan_check.py) sees it.
+static inline void wavesim_buffer_align(const __amdgpu_buffer_rsrc_t& r, uint32_t checked_off, uint32_t soff) {
+  if (((uintptr_t)r.base + checked_off + soff) & 3) wavesim::fail("buffer access at an address that is not dword-aligned");
+}
 static inline void wavesim_buffer_read(const __amdgpu_buffer_rsrc_t& r, uint32_t checked_off, uint32_t soff, void* dst, int bytes) {
+  wavesim_buffer_align(r, checked_off, soff);
   unsigned char* d = reinterpret_cast<unsigned char*>(dst);
   for (int b = 0; b < bytes; b += 4) {
     const int64_t o = (int64_t)checked_off + b;
@@ -278,6 +282,7 @@ static inline void wavesim_buffer_read(const __amdgpu_buffer_rsrc_t& r, uint32_t
   }
 }
 static inline void wavesim_buffer_write(const __amdgpu_buffer_rsrc_t& r, uint32_t checked_off, uint32_t soff, const void* src, int bytes) {
+  wavesim_buffer_align(r, checked_off, soff);
   const unsigned char* s = reinterpret_cast<const unsigned char*>(src);
   for (int b = 0; b < bytes; b += 4) {
     const int64_t o = (int64_t)checked_off + b;
@@ -310,6 +315,7 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc
   unsigned char tmp[16];
   if (size > 16) wavesim::fail("buffer_load ... lds of %d bytes", size);
   wavesim_buffer_read(r, (uint32_t)voff + (uint32_t)imm, (uint32_t)soff, tmp, size);
+  if (((uintptr_t)lds) & (size - 1) & 15) wavesim::fail("LDS-DMA destination not aligned to its %d-byte elements", size);
   wavesim::vm_push(reinterpret_cast<char*>((uintptr_t)lds) + wavesim::cur->lane * size, tmp, size);
 }
 typedef __attribute__((address_space(1))) void* wavesim_glb_vptr;

@@ -581,7 +581,7 @@ def test_results_do_not_depend_on_the_schedule(sim, monkeypatch):
     mask[1, 150:] = 0
     wav = torch.from_numpy(synth.make_waveforms(1, n_samples=20000))
     outs = {}
-    for order in ("forward", "reverse"):
+    for order in ("forward", "reverse", "random:5"):
         monkeypatch.setenv("WAVESIM_ORDER", order)
         got = []
         for tile in (8256, 4256, 4128, 2256):
@@ -597,8 +597,9 @@ def test_results_do_not_depend_on_the_schedule(sim, monkeypatch):
         got.append(o)
         got.append(_mel_patches(sim, wav, 80)["audio_patches"])
         outs[order] = got
-    for x, y in zip(outs["forward"], outs["reverse"]):
-        assert torch.equal(x.float(), y.float())
+    for other in ("reverse", "random:5"):
+        for x, y in zip(outs["forward"], outs[other]):
+            assert torch.equal(x.float(), y.float()), other
 
 
 def test_bad_arguments_are_refused_not_executed(sim, tiny_state):

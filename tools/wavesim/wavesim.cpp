@@ -59,10 +59,16 @@ int dma_late = [] { const char* e = getenv("WAVESIM_DMA"); return (e && !strcmp(
 // WAVESIM_ORDER=reverse: waves (and the lanes inside a wave) are run last to first between rendezvous points.  Results must
 // not depend on it: a kernel that only works because wave 0 happens to run first (a missing barrier, a read of another
 // wave's LDS data before its covering wait) gives different bytes under the other order.
-static int order_reverse() {
+// WAVESIM_ORDER=random:<seed>: a fresh permutation of the waves for every pass of the scheduler (every interval between two
+// workgroup barriers), lanes forward or backward at random.
+static int order_mode(unsigned* seed) {         // 0 forward, 1 reverse, 2 random
   const char* e = getenv("WAVESIM_ORDER");      // read per launch: tests flip it at run time
-  return e && !strcmp(e, "reverse");
+  if (!e) return 0;
+  if (!strcmp(e, "reverse")) return 1;
+  if (!strncmp(e, "random", 6)) { *seed = e[6] == ':' ? (unsigned)atoi(e + 7) : 1u; return 2; }
+  return 0;
 }
+static inline unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
 namespace {
 
@@ -168,15 +174,22 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
   }
   W.bar_gen = 0;
   W.bar_or[0] = W.bar_or[1] = 0;
-  const int rev = order_reverse();
+  unsigned seed = 1;
+  const int mode = order_mode(&seed);
+  seed = seed * 2654435761u + bidx.x * 97u + bidx.y * 7919u + bidx.z * 104729u;
+  int perm[MAX_THREADS / 64];
   int live = nthreads;
   while (live > 0) {
     bool progress = false;
     int at_barrier = 0;
     live = 0;
+    for (int i = 0; i < nwaves; ++i) perm[i] = mode == 1 ? nwaves - 1 - i : i;
+    if (mode == 2)
+      for (int i = nwaves - 1; i > 0; --i) { const int j = (int)(lcg(seed) % (unsigned)(i + 1)); const int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
     for (int wi = 0; wi < nwaves; ++wi) {
-      const int w = rev ? nwaves - 1 - wi : wi;
+      const int w = perm[wi];
       Wave& wv = W.waves[w];
+      const int rev = mode == 1 || (mode == 2 && (lcg(seed) & 1));
       for (;;) {
         for (int li = 0; li < wv.nlanes; ++li) {
           const int l = rev ? wv.nlanes - 1 - li : li;

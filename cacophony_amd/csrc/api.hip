@@ -469,8 +469,17 @@ struct Arena {
   T* at(size_t o) const { return reinterpret_cast<T*>(w->p + o); }
 };
 
-int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st, int ldc = 0) {
+// order (ping-pong traversal, run_audio_layers): 0 = the kernel's default tile order; 1 / 2 = one n-tile group, so that every
+// XCD owns one contiguous range of M, walked first to last / last to first
+inline void set_order(GemmArgs& g, int order) {
+  if (order) {
+    g.ngroup = g.N / 256 > 0 ? g.N / 256 : 1;
+    g.reverse = order == 2;
+  }
+}
+int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, hipStream_t st, int ldc = 0, int order = 0) {
   GemmArgs g{a, L.w, L.b, nullptr, out, M, L.out, L.in, ldc ? ldc : L.out};
+  set_order(g, order);
   return gemm_bf16(g, EPI_BF16, act, st);
 }
 // Row stride (elements) of the fused Q | K | V buffer: rows padded to a multiple of 512 elements (3H = 2304 -> 2560).
@@ -483,8 +492,9 @@ inline int qkv_ld(int H) {
   static const int pad = getenv("CACO_QKV_PAD") ? atoi(getenv("CACO_QKV_PAD")) : 1;
   return pad ? (3 * H + 511) / 512 * 512 : 3 * H;
 }
-int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st) {
+int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st, int order = 0) {
   GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out};
+  set_order(g, order);
   return gemm_bf16(g, EPI_F32, ACT_NONE, st);
 }
 #define CACO_TRY(expr)       \
@@ -531,8 +541,18 @@ int linear_resid_stats(const Lin& L, const bf16_t* a, int64_t M, float* x, bf16_
 // LayerNorm consumes the raw rows (bf16 copy xb) with gamma-scaled weights and applies mean / rstd per row in its
 // epilogue; the GEMM that produces new residual rows (out-proj, fc2) also writes xb and per-row partial sums, which a
 // tiny kernel turns into (mean, rstd).  Saves 590 MB of HBM traffic and a launch per LayerNorm.
+// CACO_PINGPONG=1 (read at every call; round 3, untimed): consecutive kernels of a layer walk the rows in OPPOSITE directions
+// inside the 8 row ranges the XCDs own (LayerNorm: layernorm_ranges_kernel; attention: contiguous clips per XCD; GEMMs: one
+// n-tile group, reversed tile list).  Every kernel then starts on the rows its producer wrote last - the part of the
+// producer's output that is still in the 256 MiB Infinity Cache - instead of on the rows that were written first and have
+// been evicted by the rest of the same output (fc1's output alone is 780 MB).  `kdir` counts kernels; its parity is the direction.
+bool pingpong_enabled() {
+  const char* e = getenv("CACO_PINGPONG");
+  return e && atoi(e) != 0;
+}
+
 int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const Arena& A, const AudioWs& w,
-                     const float* mask, int batch, int seq, int heads, float eps, hipStream_t st) {
+                     const float* mask, int batch, int seq, int heads, float eps, hipStream_t st, int* kdir = nullptr) {
   const int H = m->cfg.audio_hidden;
   const int64_t M = (int64_t)batch * seq;
   float* x = A.at<float>(w.x);
@@ -558,14 +578,18 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
     }
     return CACO_OK;
   }
+  int kd_local = 0;
+  int& kd = kdir ? *kdir : kd_local;
+  const bool pp = kdir != nullptr && pingpong_enabled();
+  auto ord = [&]() { const int o = pp ? 1 + (kd & 1) : 0; ++kd; return o; };
   for (const AudioLayer& L : layers) {
-    CACO_STAGE("audio.ln", layernorm(x, L.ln1.g, L.ln1.b, M, H, eps, nullptr, h, st));
-    CACO_STAGE("audio.gemm_qkv", linear_bf16(L.qkv, h, M, ACT_NONE, qkv, st, qkv_ld(H)));
-    CACO_STAGE("audio.attention", attention(qkv, qkv_ld(H), H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st));
-    CACO_STAGE("audio.gemm_out", linear_f32(L.o, o, M, x, x, st));
-    CACO_STAGE("audio.ln", layernorm(x, L.ln2.g, L.ln2.b, M, H, eps, nullptr, h, st));
-    CACO_STAGE("audio.gemm_fc1", linear_bf16(L.fc1, h, M, ACT_SILU, a, st));
-    CACO_STAGE("audio.gemm_fc2", linear_f32(L.fc2, a, M, x, x, st));
+    CACO_STAGE("audio.ln", layernorm(x, L.ln1.g, L.ln1.b, M, H, eps, nullptr, h, st, ord()));
+    CACO_STAGE("audio.gemm_qkv", linear_bf16(L.qkv, h, M, ACT_NONE, qkv, st, qkv_ld(H), ord()));
+    CACO_STAGE("audio.attention", attention(qkv, qkv_ld(H), H, 2 * H, mask, batch, seq, heads, H / heads, 0, o, st, ord()));
+    CACO_STAGE("audio.gemm_out", linear_f32(L.o, o, M, x, x, st, ord()));
+    CACO_STAGE("audio.ln", layernorm(x, L.ln2.g, L.ln2.b, M, H, eps, nullptr, h, st, ord()));
+    CACO_STAGE("audio.gemm_fc1", linear_bf16(L.fc1, h, M, ACT_SILU, a, st, 0, ord()));
+    CACO_STAGE("audio.gemm_fc2", linear_f32(L.fc2, a, M, x, x, st, ord()));
   }
   return CACO_OK;
 }
@@ -836,7 +860,8 @@ static int audio_forward_impl(caco_model* m, const void* patches, int32_t dtype,
     CACO_STAGE("audio.patch_embed", gemm_bf16(gpe, EPI_F32, ACT_NONE, st));
     CACO_STAGE("audio.pos_embed", add_pos_embed(x, nullptr, tinds, finds, m->enc.freq_table, M, H, nf, st));
   }
-  CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st));
+  int kdir = 1;                                   // the patch-embed GEMM was kernel 0 (first to last)
+  CACO_TRY(run_audio_layers(m, m->enc.layers, A, w, mask, batch, seq, c.audio_heads, c.audio_ln_eps, st, &kdir));
   // AudioAttentionPooler.forward, caco.py:41-79 (projections folded out of the token loop, pool.hip)
   float* pooled = A.at<float>(o_pool);                  // [B, heads, H]: softmax-weighted token means per head
   float* pv = A.at<float>(o_pv);                        // [B, H]: value projection of the pooled rows, heads concatenated

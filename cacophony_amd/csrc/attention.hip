@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
 template <int HD, bool CAUSAL, int NW, int QR>
 __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, int q_ld, int Sq, const bf16_t* __restrict__ kv, int ld,
                                                int k_off, int v_off, const float* __restrict__ key_mask, int S, int heads,
-                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
+                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows, int order) {
   constexpr int NT = NW * 64, QB = NW * 32 * QR;
   constexpr int RP = HD * 2;                   // K and V row pitch in LDS = the unpadded row (192 / 128 bytes)
   constexpr int VP = RP;
@@ -99,7 +99,11 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
     if (lin < per_clip * b8) {
       const int xcd = lin & 7, slot = lin >> 3;
       const int w = slot % per_clip;
-      b = (slot / per_clip) * 8 + xcd;
+      // order 0: clip b on XCD b % 8.  order 1 / 2 (ping-pong traversal, api.hip): XCD x serves the contiguous clips
+      // [x * b8/8, (x + 1) * b8/8) - the row range the persistent GEMMs' XCD x owns - first to last / last to first
+      const int k = slot / per_clip, nb = b8 >> 3;
+      const int kk = order == 2 ? nb - 1 - k : k;
+      b = order == 0 ? k * 8 + xcd : xcd * nb + kk;
       qb = w % gridDim.x;
       h = w / gridDim.x;
     }
@@ -346,8 +350,8 @@ template <int HD, bool CAUSAL, int NW, int QR>
 __global__ __launch_bounds__(NW * 64, QR == 1 ? 3 : 2) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
-                                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows) {
-  attention_body<HD, CAUSAL, NW, QR>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows);
+                                                               bf16_t* __restrict__ out, float scale_log2, int kv_rows, int order) {
+  attention_body<HD, CAUSAL, NW, QR>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows, order);
 }
 
 // experiment switch: CACO_ATTN_ROWS=32 keeps one query block per wave at every sequence length
@@ -359,15 +363,15 @@ int attention_rows_per_wave() {
 }  // namespace
 
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
-              int head_dim, int causal, bf16_t* out, hipStream_t st) {
-  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0);
+              int head_dim, int causal, bf16_t* out, hipStream_t st, int order) {
+  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0, order);
 }
 
 // General form: queries [batch, seq_q] rows of `q` (row stride q_ld, head h at column h*head_dim), keys / values
 // [batch, seq] rows of `kv` (row stride ld, head h at columns h*head_dim + k_off / v_off).  Cross-attention of the caption
 // decoder (RobertaSelfAttention with key_value_states, src/caco_torch/text_models/roberta.py:67-104): seq_q != seq.
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask,
-                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows) {
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows, int order) {
   if (kv_batch_rows <= 0) kv_batch_rows = seq;
   CACO_REQUIRE(kv_batch_rows >= seq, "attention: kv_batch_rows %d < seq %d", kv_batch_rows, seq);
   CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);
@@ -390,7 +394,7 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   const int qr = (!causal && seq_q > 128 && attention_rows_per_wave() != 32) ? 2 : 1;
   const dim3 grid((seq_q + NW * 32 * qr - 1) / (NW * 32 * qr), heads, batch);
 #define CACO_ATTN(HD_, C_, QR_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows)
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows, order)
 #define CACO_ATTN_QR(HD_, C_) do { if (qr == 2) CACO_ATTN(HD_, C_, 2); else CACO_ATTN(HD_, C_, 1); } while (0)
   if (head_dim == 96) {
     if (causal) CACO_ATTN(96, true, 1); else CACO_ATTN_QR(96, false);

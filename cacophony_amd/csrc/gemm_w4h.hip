@@ -222,7 +222,7 @@ int launch_w4h(const GemmArgs& p, hipStream_t st) {
   const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
   GemmArgs q = p;
   q.ngroup = p.N / 256;                     // one group: the shapes this kernel is for have at most a few n-tiles per M panel
-  q.stagger = 0;
+  if (p.reverse) q.ngroup = -q.ngroup;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), H_SMEM, st, q);
   return check_hip(hipGetLastError(), "gemm_bf16_w4h launch");
 }

@@ -223,7 +223,7 @@ int launch_w4q(const GemmArgs& p, hipStream_t st) {
     for (int d = 4; d >= 2; --d)
       if (tiles_n % d == 0) { q.ngroup = d; break; }
   }
-  q.stagger = 0;
+  if (p.reverse) q.ngroup = -q.ngroup;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), W_SMEM, st, q);
   return check_hip(hipGetLastError(), "gemm_bf16_w4q launch");
 }

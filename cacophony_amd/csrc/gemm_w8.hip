@@ -250,11 +250,8 @@ int launch_w8(const GemmArgs& p, hipStream_t st) {
     }
     if (env_g == 0) g = tiles_n;
     else if (env_g > 0) g = env_g < tiles_n ? env_g : tiles_n;
-    q.ngroup = g;
-    // start-time spread of the workgroups (units of 1024 cycles): measured without effect (0 .. 128), the epilogue is not
-    // HBM-bound; kept as an experiment switch
-    static const int env_s = getenv("CACO_W8_STAGGER") ? atoi(getenv("CACO_W8_STAGGER")) : 0;
-    q.stagger = tiles > grid ? env_s : 0;
+    if (p.ngroup > 0) g = p.ngroup < tiles_n ? p.ngroup : tiles_n;      // the caller's choice (ping-pong traversal: one group)
+    q.ngroup = p.reverse ? -g : g;       // the kernels read the direction from the sign (w4_decode)
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), W_SMEM, st, q);
   return check_hip(hipGetLastError(), "gemm_bf16_w8 launch");

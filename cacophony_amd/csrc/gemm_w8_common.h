@@ -29,7 +29,12 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 // Tile order.  The n-tiles are processed in groups of G (p.ngroup): all M panels of one group, then the next group,
 // n fastest inside a group.  A group's weight rows (G x 256 x K bf16) then stay in the XCD's 4 MiB L2 for the whole
 // pass instead of being re-streamed through it once per M panel.  Default: groups of 4 at K <= 1024 (launch_w8).
+// G < 0: the same list walked last to first (GemmArgs::reverse).
 __device__ __forceinline__ void w4_decode(int t, int tiles_n, int tiles_m, int G, int& tm, int& tn) {
+  if (G < 0) {
+    G = -G;
+    t = tiles_m * tiles_n - 1 - t;
+  }
   const int per = tiles_m * G;
   const int g = t / per;                 // groups before the last one are full
   const int n0 = g * G;

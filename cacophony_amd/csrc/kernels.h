@@ -18,7 +18,8 @@ struct GemmArgs {
   int N, K, ldc;
   int lda, ldw;         // row strides of A / W in elements; 0 = K (dense)
   int ngroup;           // gemm_x: n-tiles per L2 group (0 = all)
-  int stagger;          // persistent kernels: spread of the workgroups' start times, units of 1024 cycles (0 = none)
+  int reverse;          // persistent kernels: walk the tile list last to first (ping-pong traversal of consecutive kernels,
+                        // api.hip run_audio_layers); the launcher folds it into the sign of ngroup, the kernels read only that
   // LayerNorm folding (8-wave kernel of gemm_w4.hip only; all null = plain GEMM).
   // consumer, EPI_BF16:  out = act( rstd[m] * (acc[m,n] - mean[m] * fold_c1[n]) + bias[n] )
   //   with A = the RAW (un-normalised) rows in bf16, W = gamma-scaled weights, bias = W.beta + b  (see api.hip)
@@ -58,8 +59,10 @@ int gemm_f32(const float* A, const float* B, const float* bias, float* C, int M,
              hipStream_t st, int lda = 0, int ldb = 0);     // lda / ldb: row strides of A / B in elements (0 = K)
 
 // norm.hip
+// order: 0 = rows in block order; 1 / 2 = the rows as 8 contiguous ranges (workgroup b serves range b % 8: the ranges the
+// persistent GEMMs' XCDs own), each walked first to last (1) or last to first (2) - ping-pong traversal, api.hip
 int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
-              bf16_t* out_bf16, hipStream_t st);
+              bf16_t* out_bf16, hipStream_t st, int order = 0);
 int l2_normalize(const float* x, int rows, int dim, float* out, hipStream_t st, int ld_out = 0);   // ld_out: row stride of out (0 = dim)
 int text_embed_ln(const int64_t* ids, const int64_t* pos_ids, const float* word, const float* pos, const float* type0,
                   const float* gamma, const float* beta, int64_t rows, int seq, int dim, int vocab, int max_pos,
@@ -83,11 +86,13 @@ int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq,
 
 // attention.hip
 // qkv: bf16 [batch*seq, ld], Q at column 0, K at k_off, V at v_off (head h = columns h*head_dim.. of each)
+// order: 0 = clip b on XCD b % 8 (default); 1 / 2 = XCD x serves clips [x * B/8, (x + 1) * B/8), first to last / last to first
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
-              int head_dim, int causal, bf16_t* out, hipStream_t st);
+              int head_dim, int causal, bf16_t* out, hipStream_t st, int order = 0);
 // kv_batch_rows: rows between the first keys of two consecutive clips in `kv` (0 = seq; larger for a KV cache)
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* kv, int ld, int k_off, int v_off, const float* key_mask,
-                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows = 0);
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows = 0,
+                  int order = 0);
 
 // attention_small.hip: one wave per (clip, head, 32-query block) for seq_q, seq <= 64 at head_dim 64 (the text tower at T = 32)
 bool attention_small_ok(int seq_q, int seq, int head_dim);

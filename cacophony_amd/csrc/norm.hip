@@ -74,6 +74,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
 }
 
+// The same rows in the order the persistent GEMMs' XCDs own them (ping-pong traversal, api.hip): the row blocks form 8
+// contiguous ranges, workgroup b serves range b % 8 (the hardware deals consecutive workgroups to the 8 XCDs round-robin) and
+// walks it first to last or last to first (`desc`).  What a kernel wrote last in each range is what the next one reads first.
+template <bool NT>
+__global__ __launch_bounds__(256) void layernorm_ranges_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int64_t rows, int dim, float eps,
+                                                               float* __restrict__ of, bf16_t* __restrict__ ob, int per_range,
+                                                               int desc) {
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t blk = (int64_t)xcd * per_range + (desc ? per_range - 1 - slot : slot);
+  const int64_t row = blk * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = dim >> 2;
+  f32x4 v[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c * 64 + lane < nchunk) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + row * dim + (c * 64 + lane) * 4);
+      v[c] = NT ? __builtin_nontemporal_load(src) : *src;
+    }
+  ln_row(v, nchunk, lane, dim, gamma, beta, eps, of ? of + row * dim : nullptr, ob ? ob + row * dim : nullptr);
+}
+
 // A/B variant (-DLN_TWO_ROWS, tools/build_variant.sh; round 3, untimed): one wave owns TWO consecutive rows - twice the loads
 // in flight per wave (6 x 16 bytes instead of 3 at dim 768), half the waves, the two rows' reductions interleaved.  The
 // default kernel above reaches 0.70 of the HBM roofline; this asks whether latency per wave is what is left.
@@ -299,12 +323,22 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, float* __restric
 }  // namespace
 
 int layernorm(const float* x, const float* gamma, const float* beta, int64_t rows, int dim, float eps, float* out_f32,
-              bf16_t* out_bf16, hipStream_t st) {
+              bf16_t* out_bf16, hipStream_t st, int order) {
   CACO_REQUIRE(dim % 4 == 0 && dim > 0 && dim <= 256 * MAXC, "layernorm: dim %d must be a multiple of 4, <= %d", dim, 256 * MAXC);
   CACO_REQUIRE(rows > 0 && x && gamma && beta && (out_f32 || out_bf16), "layernorm: bad arguments");
   // streaming (nt) reads of the fp32 rows when only the bf16 copy is produced (pre-LN stacks): x is not needed again
   // before the next GEMM rewrites it, and the bf16 rows this kernel writes are what should stay cached
   static const int nt_env = getenv("CACO_LN_NT") ? atoi(getenv("CACO_LN_NT")) : 1;      // measured -1.1 % per step
+  if (order == 1 || order == 2) {
+    const int64_t nblk = (rows + 3) / 4;
+    const int per_range = (int)((nblk + 7) / 8);
+    const dim3 grid((unsigned)(per_range * 8));
+    if (nt_env && !out_f32)
+      hipLaunchKernelGGL(layernorm_ranges_kernel<true>, grid, dim3(256), 0, st, x, gamma, beta, rows, dim, eps, out_f32, out_bf16, per_range, order == 2);
+    else
+      hipLaunchKernelGGL(layernorm_ranges_kernel<false>, grid, dim3(256), 0, st, x, gamma, beta, rows, dim, eps, out_f32, out_bf16, per_range, order == 2);
+    return check_hip(hipGetLastError(), "layernorm launch");
+  }
 #ifdef LN_TWO_ROWS
   if (nt_env && !out_f32)
     hipLaunchKernelGGL(layernorm2_kernel<true>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, x, gamma, beta, rows, dim, eps, out_f32, out_bf16);

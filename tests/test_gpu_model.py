@@ -558,3 +558,14 @@ def test_audio_pooler_head_counts_match_reference(tiny_state, heads):
     other = g["emb_heads4" if heads != 4 else "emb_heads8"]
     assert cosine_rows(emb, ref).min() > COS_TOL
     assert rel_l2(emb, ref) < 0.5 * rel_l2(emb, other)
+
+
+def test_pingpong_traversal_changes_nothing_but_the_order(full_model, monkeypatch):
+    """CACO_PINGPONG=1 (same case as tests/test_wavesim.py, at a batch the persistent kernels are the default for): pure
+    re-ordering of independent work, so the embeddings are bitwise those of the default order."""
+    wav = torch.from_numpy(synth.make_waveforms(44, start=3)).to(DEV)          # not a multiple of 8: the last clips keep the plain order
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CACO_PINGPONG", flag)
+        outs[flag] = full_model.encode_audio(wav).cpu().numpy()
+    np.testing.assert_array_equal(outs["1"], outs["0"])

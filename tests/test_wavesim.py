@@ -762,3 +762,27 @@ def _full_config_golden(sim, full_state):
     at = torch.empty(4, 4)
     simlib.check(sim.caco_similarity(P(a_n), 4, P(t_n), 4, 768, scale, P(at), 4, None))
     assert np.abs(at.numpy() - g["at_logits"]).max() < 1e-3 * scale
+
+
+@pytest.mark.parametrize("B,n", [(9, 20480), (16, 5120), (3, 41000)])
+def test_pingpong_traversal_changes_nothing_but_the_order(sim, tiny_state, monkeypatch, B, n):
+    """CACO_PINGPONG=1: consecutive kernels of a layer walk the rows in opposite directions inside the 8 ranges the XCDs own
+    (reversed tile lists, range-ordered LayerNorm, contiguous clips per XCD in attention).  Pure re-ordering of independent
+    work: hidden states and embeddings are BITWISE those of the default order - for batches that are and are not multiples
+    of 8, with row counts that leave ragged ranges."""
+    a, t, cc = C.tiny_configs(2)
+    m = simlib.SimModel(a, None, cc).load_state_dict({k: v for k, v in tiny_state.items() if k.startswith("audio_")})
+    wav = np.stack([synth.make_waveform(90 + i, n_samples=n) for i in range(B)]).astype(np.float32)
+    ab = _mel_patches(sim, wav, max(8, n * 8 // 160 // 16))
+    sim.caco_set_gemm_tile(8256)
+    try:
+        outs = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("CACO_PINGPONG", flag)
+            emb, hid = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
+            outs[flag] = (emb.numpy().copy(), hid.numpy().copy())
+    finally:
+        sim.caco_set_gemm_tile(256)
+    np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+    np.testing.assert_array_equal(outs["1"][0], outs["0"][0])
+    assert np.isfinite(outs["1"][0]).all()

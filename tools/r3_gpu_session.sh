@@ -43,6 +43,7 @@ for rep in 1 2; do
   ab pool_fuse     CACO_POOL_FUSE=1
   ab all3          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1
   ab ngroup_off    CACO_W_NGROUP=0
+  ab pingpong      CACO_PINGPONG=1             # consecutive kernels walk the rows in opposite directions (one n-tile group): compare with ngroup_off
   ab text_w4h      CACO_W4H_MAX_TILES=128      # the text tower's N = 768 GEMMs (96 tiles of 256 x 256) on 128 x 256 tiles (gemm_w4h.hip)
   ab text_n768_128 CACO_W8_MIN_TILES=200      # the text tower's N = 768 GEMMs (192 tile units) on the 128 x 128 kernel instead of w8
 done
@@ -66,6 +67,10 @@ if want pmc; then
   bash tools/pmc_run.sh r3_pmc_attn attention_kernel -- python tools/attn_bench.py > /dev/null 2>&1
   bash tools/pmc_run.sh r3_pmc_mel mel_kernel -- python tools/mel_bench.py > /dev/null 2>&1
   for k in fc1 attn mel; do for f in sq1 sq2 sq3 tcc1 tcc2; do cat gpurun_out/r3_pmc_$k/$f.csv gpurun_out/r3_pmc_$k/$f.dur > "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
+  # fabric reads of every kernel of the step, default order vs ping-pong traversal (does the Infinity Cache keep a producer's tail?)
+  bash tools/pmc_run.sh r3_pmc_step_ng0 kernel -- env CACO_W_NGROUP=0 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  bash tools/pmc_run.sh r3_pmc_step_pp kernel -- env CACO_PINGPONG=1 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  for k in step_ng0 step_pp; do for f in tcc1 tcc2; do cp gpurun_out/r3_pmc_$k/$f.csv "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
   bash tools/pmc_hbm.sh r3_hbm fc1 256 > /dev/null 2>&1; cp gpurun_out/r3_hbm/hbm_traffic.json "$OUT/" 2>/dev/null
   ls "$OUT"
 fi

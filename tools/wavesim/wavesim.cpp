@@ -275,8 +275,10 @@ void fail(const char* fmt, ...) {
   abort();
 }
 
-void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body) {
+void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what) {
   if (lds_bytes > DYN_LDS) fail("launch with %zu bytes of dynamic LDS", lds_bytes);
+  if (const char* tr = getenv("WAVESIM_TRACE"))            // WAVESIM_TRACE=1: one line per launch on stderr
+    if (atoi(tr)) fprintf(stderr, "[wavesim] launch %s grid (%u,%u,%u) block %u lds %zu\n", what, grid.x, grid.y, grid.z, block.x, lds_bytes);
   const long nblocks = (long)grid.x * grid.y * grid.z;
   static const int max_threads = [] {
     const char* e = getenv("WAVESIM_THREADS");

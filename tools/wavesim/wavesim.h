@@ -82,7 +82,7 @@ void wave_rendezvous(const void* site);         // returns when every live lane 
 void block_barrier();
 int block_barrier_or(int pred);                 // __syncthreads_or: barrier + OR of every live lane's predicate
 char* dyn_lds();                                // the workgroup's dynamic LDS (160 KiB)
-void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body);
+void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what = "");
 [[noreturn]] void fail(const char* fmt, ...);
 
 inline unsigned char* xput() { return cur->wave->x[cur->wave->gen & 1][cur->lane]; }
@@ -174,7 +174,7 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
   do {                                                                                                     \
     const dim3 g_ = (grid), b_ = (block);                                                                  \
     wavesim::launch(wavesim::idx3{g_.x, g_.y, g_.z}, wavesim::idx3{b_.x, b_.y, b_.z}, (size_t)(lds),        \
-                    [&]() { kern(__VA_ARGS__); });                                                          \
+                    [&]() { kern(__VA_ARGS__); }, #kern);                                                   \
   } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------

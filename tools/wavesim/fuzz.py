@@ -192,6 +192,7 @@ def fuzz_model(sim, rng, log):
     os.environ["CACO_ATTN_SMALL"] = "1" if rng.random() < 0.5 else "0"
     os.environ["CACO_POS_FUSE"] = "1" if rng.random() < 0.5 else "0"
     os.environ["CACO_POOL_FUSE"] = "1" if rng.random() < 0.5 else "0"
+    os.environ["CACO_PINGPONG"] = "1" if rng.random() < 0.5 else "0"
     tile = int(rng.choice([256, 8256, 128]))
     sim.caco_set_gemm_tile(tile)
     m.set_ln_fold(int(rng.random() < 0.3))
@@ -215,11 +216,11 @@ def fuzz_model(sim, rng, log):
     assert np.isfinite(ea).all() and np.isfinite(et).all()
     ca, ct = cosine_rows(ea, ra).min(), cosine_rows(et, rt).min()
     desc = (f"model B {B} n {n} lens {lens} T {T} tile {tile} small {os.environ['CACO_ATTN_SMALL']} fuse {os.environ['CACO_POS_FUSE']} "
-            f"pool {os.environ['CACO_POOL_FUSE']}")
+            f"pool {os.environ['CACO_POOL_FUSE']} pp {os.environ['CACO_PINGPONG']}")
     assert ca > 0.999 and ct > 0.999, (desc, ca, ct)
     sim.caco_set_gemm_tile(256)
     m.set_ln_fold(0)
-    os.environ["CACO_ATTN_SMALL"] = os.environ["CACO_POS_FUSE"] = os.environ["CACO_POOL_FUSE"] = "0"
+    os.environ["CACO_ATTN_SMALL"] = os.environ["CACO_POS_FUSE"] = os.environ["CACO_POOL_FUSE"] = os.environ["CACO_PINGPONG"] = "0"
     log.append(desc + f" cos {ca:.5f} {ct:.5f}")
 
 

@@ -16,5 +16,8 @@ bash tools/build_variant.sh ln_2rows norm.hip -DLN_TWO_ROWS
 bash tools/build_variant.sh a_nt gemm_w8.hip -DW8_A_AUX=2
 bash tools/build_variant.sh w_nt gemm_w8.hip -DW8_W_AUX=2
 bash tools/build_variant.sh a_sc1 gemm_w8.hip -DW8_A_AUX=16
+# epilogue stores with the default cache policy (instead of nt / sc1): for the ping-pong experiment, in case the streaming
+# hints keep a producer's output out of the Infinity Cache
+bash tools/build_variant.sh st_plain gemm_w8.hip -DW8_ST_AUX=0 -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
 python -m cacophony_amd.build --force >/dev/null
 ls -la cacophony_amd/_variants/*.so

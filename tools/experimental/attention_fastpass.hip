@@ -395,15 +395,16 @@ int attention_rows_per_wave() {
 }  // namespace
 
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
-              int head_dim, int causal, bf16_t* out, hipStream_t st) {
-  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0);
+              int head_dim, int causal, bf16_t* out, hipStream_t st, int order) {
+  return attention_qkv(qkv, ld, seq, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, head_dim, causal, out, st, 0, order);
 }
 
 // General form: queries [batch, seq_q] rows of `q` (row stride q_ld, head h at column h*head_dim), keys / values
 // [batch, seq] rows of `kv` (row stride ld, head h at columns h*head_dim + k_off / v_off).  Cross-attention of the caption
 // decoder (RobertaSelfAttention with key_value_states, src/caco_torch/text_models/roberta.py:67-104): seq_q != seq.
 int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask,
-                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows) {
+                  int batch, int seq, int heads, int head_dim, int causal, bf16_t* out, hipStream_t st, int kv_batch_rows, int order) {
+  (void)order;      // (the clip order of the ping-pong experiment is not part of this variant: default mapping)
   if (kv_batch_rows <= 0) kv_batch_rows = seq;
   CACO_REQUIRE(kv_batch_rows >= seq, "attention: kv_batch_rows %d < seq %d", kv_batch_rows, seq);
   CACO_REQUIRE(batch > 0 && seq > 0 && seq_q > 0 && heads > 0, "attention: bad shape B=%d Sq=%d S=%d heads=%d", batch, seq_q, seq, heads);

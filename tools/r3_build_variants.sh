@@ -20,4 +20,16 @@ bash tools/build_variant.sh a_sc1 gemm_w8.hip -DW8_A_AUX=16
 # hints keep a producer's output out of the Infinity Cache
 bash tools/build_variant.sh st_plain gemm_w8.hip -DW8_ST_AUX=0 -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
 python -m cacophony_amd.build --force >/dev/null
-ls -la cacophony_amd/_variants/*.so
+# every variant must resolve all its symbols (a kernel-side signature change breaks the parked attention variant silently otherwise)
+python - <<'PY'
+import ctypes, glob, sys
+bad = 0
+for f in sorted(glob.glob("cacophony_amd/_variants/*.so")):
+    try:
+        ctypes.CDLL(f)
+        print("ok  ", f)
+    except OSError as e:
+        bad += 1
+        print("FAIL", f, str(e)[:160])
+sys.exit(1 if bad else 0)
+PY

@@ -444,7 +444,9 @@ def main():
                                    "(one RCCL all-gather of the packed [256,2,768] fp32 banks, local [256, N*256] row block)",
                        "global_batch": world * B_PER_GPU, "clip": "10 s @ 16 kHz (160000 samples, 500 patches, 496 valid)",
                        "caption_tokens": TEXT_LEN, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)",
-                       "gemm_tile": int(lib.caco_set_gemm_tile(0)) if lib is not None else None},
+                       "gemm_tile": int(lib.caco_set_gemm_tile(0)) if lib is not None else None,
+                       # run-time switches in force: an A/B line says what it measured
+                       "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("CACO_") and k != "CACO_BENCH_DRYRUN"}},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extra, "stages": stages, "outputs_finite": finite,
         }
         if DRYRUN:

@@ -49,7 +49,9 @@ def panel_order(ranges, desc):
     return out
 
 
-def run(pingpong, layers=3, cap=256 * MB):
+def run(pingpong, layers=3, cap=256 * MB, read_alloc=True):
+    """read_alloc=False: reads do not allocate (what streaming loads would do if the `nt` hint reaches this cache): every
+    buffer of the layer is consumed once, so only written lines are worth keeping."""
     cache, k, per_layer = LRU(cap), 0, []
     for layer in range(layers):
         miss = total = 0
@@ -59,8 +61,12 @@ def run(pingpong, layers=3, cap=256 * MB):
             for p in panel_order(ranges, desc):
                 for b in reads:
                     total += SIZE[b]
-                    if not cache.touch((b, p), SIZE[b]):
+                    if (b, p) in cache.d:
+                        cache.d.move_to_end((b, p))
+                    else:
                         miss += SIZE[b]
+                        if read_alloc:
+                            cache.touch((b, p), SIZE[b])
                 for b in writes:
                     cache.touch((b, p), SIZE[b])
             k += 1
@@ -69,6 +75,8 @@ def run(pingpong, layers=3, cap=256 * MB):
 
 
 if __name__ == "__main__":
+    d, p = run(False, read_alloc=False), run(True, read_alloc=False)
+    print(f"reads that do not allocate, 256 MiB: from HBM  default {d[0] / 1e9:.2f} GB   ping-pong {p[0] / 1e9:.2f} GB")
     for cap in (256, 192, 128):
         d, p = run(False, cap=cap * MB), run(True, cap=cap * MB)
         print(f"cache {cap:3d} MiB: reads per layer {d[1] / 1e9:.2f} GB; from HBM  default {d[0] / 1e9:.2f} GB   ping-pong {p[0] / 1e9:.2f} GB"

@@ -60,7 +60,7 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/nul
   cat "$OUT/pytest_fastpass.txt"
   (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
   cat "$OUT/ab_variants.txt"
-  (CACO_PINGPONG=1 timeout 600 bash tools/ab_bench.sh 2 default st_plain ln_nt) > "$OUT/ab_variants_pingpong.txt" 2>&1     # ping-pong x store policy
+  (CACO_PINGPONG=1 timeout 600 bash tools/ab_bench.sh 2 default st_plain ln_nt a_nt) > "$OUT/ab_variants_pingpong.txt" 2>&1     # ping-pong x store policy
   cat "$OUT/ab_variants_pingpong.txt"
 fi
 # PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)

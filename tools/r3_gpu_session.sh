@@ -42,6 +42,7 @@ for rep in 1 2; do
   ab pos_fuse      CACO_POS_FUSE=1
   ab pool_fuse     CACO_POOL_FUSE=1
   ab all3          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1
+  ab ln_fold       CACO_LN_FOLD=1              # round 2: a wash; its epilogues lost their 32 spilled SGPRs with the round-3 epilogue change
   ab ngroup_off    CACO_W_NGROUP=0
   ab pingpong      CACO_PINGPONG=1             # consecutive kernels walk the rows in opposite directions (one n-tile group): compare with ngroup_off
   ab text_w4h      CACO_W4H_MAX_TILES=128      # the text tower's N = 768 GEMMs (96 tiles of 256 x 256) on 128 x 256 tiles (gemm_w4h.hip)

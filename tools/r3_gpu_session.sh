@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 if want truth; then
 echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
-(timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -25) > "$OUT/pytest_gpu.txt"
+(timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -40) > "$OUT/pytest_gpu.txt"
 tail -3 "$OUT/pytest_gpu.txt"
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > "$OUT/smoke.txt"
 cat "$OUT/smoke.txt"

@@ -351,3 +351,78 @@ def test_drivers_on_the_device(tiny_state):
     assert t.vocab_size == TEXT_VOCAB
     model = CACO(a, t, cc, device="cuda:0").load_state_dict(tiny_state)
     _check_drivers(model, expect_cuda=True)
+
+
+def test_device_test_body_on_the_simulator(monkeypatch, tiny_state):
+    """The GPU case above with the REAL kernels - the mel front end with per-clip lengths, both towers, the exact-fp32
+    similarity through the banks' strides and the top-k selection in both directions - executed by the wavesim build of the
+    kernel sources (tools/wavesim) behind stand-ins that make the same C-ABI calls as frontend.py / model.py / retrieval.py
+    do.  CPU only; what it adds to the oracle dry run is the device code of the scoring path under the drivers."""
+    from tests import simlib
+    if not simlib.available():
+        pytest.skip("no host clang++ for the wavesim build")
+    import ctypes
+    sim = simlib.load()
+    P = simlib.ptr
+    a, t, cc = C.tiny_configs(1)                 # one layer of each tower (the first layer's weights of the 2-layer state): half the time
+    m = simlib.SimModel(a, t, cc).load_state_dict(tiny_state)
+
+    class SimBackedModel:
+        logit_scale = torch.tensor(float(cc.logit_scale_init_value))
+
+        def get_audio_embedding(self, audio_patches, audio_time_inds, audio_freq_inds, audio_mask, deterministic=True,
+                                return_hidden_state=True, normalize=False):
+            emb, hid = m.audio_forward(audio_patches, audio_time_inds, audio_freq_inds, audio_mask, normalize=normalize)
+            return (emb, hid) if return_hidden_state else emb
+
+        def get_text_embedding(self, text_input_ids, text_mask, position_ids=None, deterministic=True, return_hidden_state=True,
+                               normalize=False):
+            emb, hid = m.text_forward(text_input_ids, text_mask, normalize=normalize, position_ids=position_ids)
+            return (emb, hid) if return_hidden_state else emb
+
+    def prepare_audio_batch(audio, datasetconfig, device=None, lengths=None):     # frontend.prepare_audio_batch on a list of clips
+        assert isinstance(audio, list)
+        lens = torch.tensor([len(c) for c in audio], dtype=torch.int64)
+        n = int(lens.max())
+        wav = torch.zeros(len(audio), n)
+        for i, c in enumerate(audio):
+            wav[i, : len(c)] = torch.as_tensor(np.asarray(c, np.float32))
+        S = datasetconfig.patches_seq_len
+        out = {"audio_patches": torch.empty(len(audio), S, 256), "audio_time_inds": torch.empty(len(audio), S),
+               "audio_freq_inds": torch.empty(len(audio), S), "audio_mask": torch.empty(len(audio), S)}
+        simlib.check(sim.caco_mel_patches_lens(P(wav), P(lens), len(audio), n, S, 0.2, 0.9, P(out["audio_patches"]), 0,
+                                               P(out["audio_time_inds"]), P(out["audio_freq_inds"]), P(out["audio_mask"]), None))
+        return out
+
+    def prepare_text_batch(text, tokenizer, max_text_len, device=None):
+        tok = tokenizer([text], padding="max_length", truncation=True, max_length=max_text_len, return_tensors="pt")
+        return {"text_input_ids": tok["input_ids"], "text_mask": tok["attention_mask"]}
+
+    def similarity(x, y, scale=1.0):
+        x, y = x.float().contiguous(), y.float().contiguous()
+        out = torch.empty(x.shape[0], y.shape[0])
+        simlib.check(sim.caco_similarity_ld(P(x), x.shape[0], x.stride(0), P(y), y.shape[0], y.stride(0), x.shape[1], float(scale),
+                                            P(out), out.stride(0), None))
+        return out
+
+    def topk(s, k, dim=1):                                                          # retrieval.topk: dim 0 through the strides
+        rows, cols, rs, cs = (s.shape[0], s.shape[1], s.stride(0), s.stride(1)) if dim == 1 else (s.shape[1], s.shape[0], s.stride(1), s.stride(0))
+        k = min(int(k), cols)
+        idx = torch.empty(rows, k, dtype=torch.int32)
+        simlib.check(sim.caco_topk(P(s), rows, cols, rs, cs, k, P(idx), None, None))
+        return idx
+
+    def zs_scores(audio_emb, class_text_emb, target_idx, logit_scale=0.0, ks=(1,)):
+        idx = topk(similarity(audio_emb, class_text_emb, float(np.exp(logit_scale))), int(max(ks))).numpy()
+        tgt = np.asarray(target_idx).astype(np.int64).reshape(-1)
+        return {str(int(k)): float((idx[:, :int(k)] == tgt[:, None]).any(axis=1).mean()) for k in ks}
+
+    def retrieval_scores(audio_emb, text_emb, k=10, sim=None):
+        logits = similarity(text_emb, audio_emb, 1.0)
+        return logits, topk(logits, k, dim=0), topk(logits, k, dim=1)
+
+    monkeypatch.setattr(frontend, "prepare_audio_batch", prepare_audio_batch)
+    monkeypatch.setattr(frontend, "prepare_text_batch", prepare_text_batch)
+    monkeypatch.setattr(retrieval, "zs_classification_scores", zs_scores)
+    monkeypatch.setattr(retrieval, "audio_retrieval_scores", retrieval_scores)
+    _check_drivers(SimBackedModel(), expect_cuda=False)

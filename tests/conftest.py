@@ -10,6 +10,10 @@ if REPO not in sys.path:
 
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
+if os.environ.get("CACO_GPU_ON_SIM") == "1":          # opt-in: the `-m gpu` test bodies on tools/wavesim (tests/fakecuda.py)
+    from tests import fakecuda
+    fakecuda.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")

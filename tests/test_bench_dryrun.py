@@ -64,3 +64,34 @@ def test_bench_step_closure_with_size_check_on_equal_shards():
 def test_bench_control_flow_single_process():
     out = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1"])
     assert out["n_gpus"] == 1 and out["ms_per_step"] >= 1.9 and out["cpu_baseline"] is None
+
+
+def test_bench_real_step_and_profile_pass_on_the_simulator():
+    """Not the dry run: bench.py's real branch - library load, create_caco_model, make_step over the kernels, the per-launch
+    profile pass, the roofline object - on tools/wavesim (tests/bench_on_sim.py: 2 pairs, one layer per tower).  Checks the
+    contract of the printed line; every number in it is simulator wall-clock."""
+    import pytest
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import simlib
+    if not simlib.available():
+        pytest.skip("no host clang++ for tools/wavesim")
+    env = {k: v for k, v in os.environ.items() if k != "CACO_BENCH_DRYRUN"}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench_on_sim.py")], cwd=REPO, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["n_gpus"] == 1 and out["outputs_finite"] is True
+    assert out["unit"] == "pairs/s" and out["dtype"] == "bf16" and out["vs_baseline"] is None and "workload" in out["config"]
+    rf = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "note"):
+        assert key in rf, key
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["avg_launch_ms"] > 0
+    st = out["stages"]
+    for name in ("mel.patches", "audio.patch_embed", "audio.gemm_qkv", "audio.attention", "audio.gemm_out", "audio.gemm_fc1",
+                 "audio.gemm_fc2", "audio.ln", "text.attention", "text.gemm_fc1", "similarity"):
+        assert name in st and st[name]["launches_per_step"] >= 1, name

@@ -105,10 +105,12 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, srcs))
     if force or not _newer(lib, objs):
-        cmd = [CXX, "-shared", "-fPIC", "-o", lib, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else [])
+        tmp = f"{lib}.{os.getpid()}.tmp"           # link beside it and rename: a process that has the old library mapped keeps it
+        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, lib)
         if verbose:
             print(f"[wavesim] linked {lib}")
     return lib

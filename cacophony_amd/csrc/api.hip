@@ -36,17 +36,17 @@ int check_hip(hipError_t e, const char* what) {
 // per (kernel, device): dynamic-LDS attribute set once; per device: CU count (kernels.h)
 int prepare_launch(const void* kern, int dyn_lds_bytes, int* num_cu) {
   static std::mutex mu;
-  static std::map<std::pair<const void*, int>, bool> attr_done;
+  static std::map<std::pair<const void*, int>, int> attr_bytes;     // largest size declared so far (a kernel's LDS may depend on the shape)
   static int cus[CACO_MAX_DEVICES] = {};
   int dev = 0;
   CACO_HIP(hipGetDevice(&dev));
   CACO_REQUIRE(dev >= 0 && dev < CACO_MAX_DEVICES, "device index %d out of range", dev);
   std::lock_guard<std::mutex> lk(mu);
   if (dyn_lds_bytes > 0) {
-    bool& done = attr_done[std::make_pair(kern, dev)];
-    if (!done) {
+    int& have = attr_bytes[std::make_pair(kern, dev)];
+    if (dyn_lds_bytes > have) {
       CACO_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_lds_bytes));
-      done = true;
+      have = dyn_lds_bytes;
     }
   }
   if (num_cu) {

@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -275,8 +276,22 @@ void fail(const char* fmt, ...) {
   abort();
 }
 
-void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what) {
+static std::mutex g_attr_mu;
+static std::map<const void*, int> g_attr_lds;
+void declare_dyn_lds(const void* fn, int bytes) {
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  g_attr_lds[fn] = bytes;
+}
+
+void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what, const void* fn) {
   if (lds_bytes > DYN_LDS) fail("launch with %zu bytes of dynamic LDS", lds_bytes);
+  if (lds_bytes > 64 * 1024 && fn) {      // above the default limit the kernel must have been given the attribute, at least this large
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    auto it = g_attr_lds.find(fn);
+    if (it == g_attr_lds.end() || (size_t)it->second < lds_bytes)
+      fail("launch of %s with %zu bytes of dynamic LDS but hipFuncAttributeMaxDynamicSharedMemorySize = %d", what, lds_bytes,
+           it == g_attr_lds.end() ? 0 : it->second);
+  }
   if (const char* tr = getenv("WAVESIM_TRACE"))            // WAVESIM_TRACE=1: one line per launch on stderr
     if (atoi(tr)) fprintf(stderr, "[wavesim] launch %s grid (%u,%u,%u) block %u lds %zu\n", what, grid.x, grid.y, grid.z, block.x, lds_bytes);
   const long nblocks = (long)grid.x * grid.y * grid.z;

@@ -83,7 +83,8 @@ void wave_rendezvous(const void* site);         // returns when every live lane 
 void block_barrier();
 int block_barrier_or(int pred);                 // __syncthreads_or: barrier + OR of every live lane's predicate
 char* dyn_lds();                                // the workgroup's dynamic LDS (160 KiB)
-void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what = "");
+void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>& body, const char* what = "", const void* fn = nullptr);
+void declare_dyn_lds(const void* fn, int bytes);      // hipFuncSetAttribute(MaxDynamicSharedMemorySize): required above 64 KiB
 [[noreturn]] void fail(const char* fmt, ...);
 
 inline unsigned char* xput() { return cur->wave->x[cur->wave->gen & 1][cur->lane]; }
@@ -161,7 +162,7 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
-static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void* fn, hipFuncAttribute, int v) { wavesim::declare_dyn_lds(fn, v); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "wavesim"; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
@@ -179,7 +180,7 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
   do {                                                                                                     \
     const dim3 g_ = (grid), b_ = (block);                                                                  \
     wavesim::launch(wavesim::idx3{g_.x, g_.y, g_.z}, wavesim::idx3{b_.x, b_.y, b_.z}, (size_t)(lds),        \
-                    [&]() { kern(__VA_ARGS__); }, #kern);                                                   \
+                    [&]() { kern(__VA_ARGS__); }, #kern, reinterpret_cast<const void*>(+kern));                                                 \
   } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 //
 // Opt-in until it has run on hardware (CACO_ATTN_SMALL=1, see attention.hip::attention_qkv); verified on the wavesim build
 // against the same checker as the big kernel (tests/test_wavesim.py).
+// a kernel that has not run on hardware yet: the intra-wave LDS hand-offs are also fenced for the compiler (common.h)
+#define CACO_WAVE_SYNC_FENCE 1
 #include "common.h"
 #include "kernels.h"
 

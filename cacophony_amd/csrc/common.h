@@ -14,10 +14,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // CACO_WAVE_LDS_SYNC(): lanes of ONE wave hand data to each other through LDS at this point (one lane's ds_write, another
 // lane's ds_read) with no workgroup barrier in between.  On the hardware a wave executes in lockstep and the compiler keeps
-// the program order of the may-alias LDS accesses, so in the product build the macro expands to NOTHING (the ISA is the
-// same with and without it); the functional simulator (tools/wavesim: a lane is a fiber) makes it a wave rendezvous.
-#ifdef WAVESIM
+// the program order of the may-alias LDS accesses, so in the product build the macro expands to NOTHING in the kernels that
+// were verified on hardware in that form (their ISA keeps the ds_write -> s_waitcnt -> ds_read order); the functional
+// simulator (tools/wavesim: a lane is a fiber) makes it a wave rendezvous.  A translation unit that defines
+// CACO_WAVE_SYNC_FENCE first (the round-3 kernels no GPU has run yet) gets wavefront-scope fences around a wave barrier
+// instead: no instruction is emitted, but the compiler may not move an LDS access across the mark whatever it can prove
+// about the addresses.
+#if defined(WAVESIM)
 #define CACO_WAVE_LDS_SYNC() wavesim_wave_sync()
+#elif defined(CACO_WAVE_SYNC_FENCE)
+#define CACO_WAVE_LDS_SYNC()                                  \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
 #else
 #define CACO_WAVE_LDS_SYNC() ((void)0)
 #endif

@@ -11,6 +11,8 @@
 //   K-loop   gemm_w8.hip's: P0 P1 P2 | vmcnt(4) lgkmcnt(0) s_barrier | P3, four A pieces per wave and K-tile (as in w8) and
 //            eight W pieces (w8: four)
 //   epilogue gemm_w8_epilogue.h, plain forms (bias; bias + residual)
+// a kernel that has not run on hardware yet: the intra-wave LDS hand-offs are also fenced for the compiler (common.h)
+#define CACO_WAVE_SYNC_FENCE 1
 #include "common.h"
 #include "kernels.h"
 #include "gemm_w8_common.h"

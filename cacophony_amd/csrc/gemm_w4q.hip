@@ -21,6 +21,8 @@
 //   Registers: 256 accumulators + two X sets of 4 and two W sets of 8 fragments (96) = 352 + addressing.
 //
 // Reference ops replaced: as gemm_w8.hip.
+// a kernel that has not run on hardware yet: the intra-wave LDS hand-offs are also fenced for the compiler (common.h)
+#define CACO_WAVE_SYNC_FENCE 1
 #include "common.h"
 #include "kernels.h"
 #include "gemm_w8_common.h"

@@ -31,7 +31,7 @@ def bf16(x):
     return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 rng = np.random.default_rng(0)
 # exact-size allocations: every array below is exactly as large as the call says
-for tile in (128, 2256, 8256):
+for tile in (128, 2256, 8256, 4256, 4128):
     lib.caco_set_gemm_tile(tile)
     for (M, N, K, act) in ((301, 256, 128, 1), (77, 768, 64, 0), (515, 512, 192, 2)):
         a, w, b = bf16(rng.standard_normal((M, K))), bf16(rng.standard_normal((N, K)) / math.sqrt(K)), rng.standard_normal(N).astype(np.float32)
@@ -70,6 +70,7 @@ for k, v in state.items():
 chk(lib.caco_finalize_weights(h), "finalize")
 for flags in (("0", "0"), ("1", "1")):
     os.environ["CACO_POS_FUSE"], os.environ["CACO_ATTN_SMALL"] = flags
+    os.environ["CACO_POOL_FUSE"] = os.environ["CACO_PINGPONG"] = flags[0]
     lib.caco_set_gemm_tile(8256 if flags[0] == "1" else 256)
     wav = (rng.standard_normal((3, 33000)) * 0.1).astype(np.float32)
     emb = np.zeros((3, 768), np.float32)

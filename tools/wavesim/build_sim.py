@@ -58,7 +58,7 @@ def _newer(out, deps):
 
 
 def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, verbose: bool = True, replace=None, defines=(),
-          tag: str = "") -> str:
+          tag: str = "", tsan: bool = False) -> str:
     """replace = {"attention.hip": "/path/to/variant.hip"}: a kernel source swapped for an experimental one (tools/experimental),
     defines = ("-DATTN_FAST_PASS", ...): extra compiler flags; both need a `tag` (object files and library are kept apart)."""
     replace = dict(replace or {})
@@ -75,7 +75,9 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
         os.path.join(HERE, "wavesim.h"), os.path.join(INCLUDE, "caco_hip.h"), os.path.abspath(__file__)]
     flags = FLAGS + list(defines) + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
-    tag = ("." + tag if tag else "") + (".asan" if asan else "")
+    if tsan:                                    # kernels instrumented, the runtime (wavesim.cpp) only annotated: see wavesim.cpp
+        flags = flags + ["-DWAVESIM_TSAN"]
+    tag = ("." + tag if tag else "") + (".asan" if asan else "") + (".tsan" if tsan else "")
 
     def one(src):
         path = src if os.path.isabs(src) else os.path.join(CSRC, src)
@@ -93,7 +95,8 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
                 f.write(f'#line 1 "{path}"\n' + t)
         else:
             gen = path
-        cmd = [CXX, *flags, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
+        san = ["-fsanitize=thread"] if (tsan and base.endswith(".hip")) else []
+        cmd = [CXX, *flags, *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{base}:\n{r.stdout}\n{r.stderr}")
@@ -106,7 +109,7 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         objs = list(ex.map(one, srcs))
     if force or not _newer(lib, objs):
         tmp = f"{lib}.{os.getpid()}.tmp"           # link beside it and rename: a process that has the old library mapped keeps it
-        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else [])
+        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else []) + (["-fsanitize=thread"] if tsan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -120,4 +123,6 @@ if __name__ == "__main__":
     extra = []
     if "--extra" in sys.argv:
         extra = sys.argv[sys.argv.index("--extra") + 1:]
-    build(force="--force" in sys.argv, asan="--asan" in sys.argv, extra=extra)
+    tsan = "--tsan" in sys.argv
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv, extra=extra, tsan=tsan,
+          lib=os.path.join(HERE, "libcaco_sim_tsan.so") if tsan else LIB)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""ThreadSanitizer run of the kernels on the wavesim build (build_sim.py --tsan): one TSan fiber per lane, fiber switches
+carry no synchronisation, and the only happens-before edges inside a launch are the hardware's - a workgroup barrier, a
+wave-level operation / CACO_WAVE_LDS_SYNC() within its wave.  Reported: two lanes of different waves touching the same LDS
+bytes with no barrier between them, two workgroups touching the same global bytes in one launch (workgroups are dealt
+round-robin over WAVESIM_THREADS workers; those of one worker are ordered, so the run is repeated with 2 and 3 workers).
+
+    python tools/wavesim/tsan_check.py            # self-test (a planted LDS race and a planted global race must be reported,
+                                                  # their barrier-ed twins must not), then the driver of asan_check.py
+
+Exit status 0 and "TSAN CLEAN" on the last line = self-test behaved and the library produced no report."""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+SELFTEST = r'''
+import ctypes as C, numpy as np, sys
+lib = C.CDLL(LIB)
+P = lambda a: C.c_void_p(a.ctypes.data)
+a = np.arange(64, dtype=np.float32); o = np.zeros(64, np.float32); z = np.zeros(128, np.float32)
+if WHICH == "clean":
+    lib.selftest_handoff(P(a), P(o), 1); assert (o == a[::-1] * 2).all()
+    lib.selftest_overlap(P(z), 64)
+elif WHICH == "lds":
+    lib.selftest_handoff(P(a), P(o), 0)
+else:
+    lib.selftest_overlap(P(z), 32)
+print("DRIVER DONE")
+'''
+
+
+def sites(err):
+    """Unique (kernel source line, kernel source line) pairs of the reports."""
+    out = set()
+    for rep in err.split("WARNING: ThreadSanitizer: data race")[1:]:
+        frames = re.findall(r"#0 \S+.*? (/\S+?:\d+)(?::\d+)? \(", rep)
+        out.add(tuple(sorted(os.path.relpath(f, REPO) for f in frames[:2])))
+    return sorted(out)
+
+
+def run(code, lib, rt, threads):
+    env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", WAVESIM_THREADS=str(threads),
+               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\nLIB = {lib!r}\n" + code], env=env, capture_output=True, text=True)
+    return r, sites(r.stderr)
+
+
+def main():
+    sys.path.insert(0, HERE)
+    import asan_check
+    import build_sim
+    lib = build_sim.build(tsan=True, lib=os.path.join(HERE, "libcaco_sim_tsan.so"), verbose=False,
+                          extra=[os.path.join(HERE, "selftest", "race_selftest.hip")])
+    rt = subprocess.run([build_sim.CXX, "-print-file-name=libclang_rt.tsan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    ok = True
+    for which, expect in (("clean", 0), ("lds", 1), ("global", 1)):
+        r, s = run(f"WHICH = {which!r}\n" + SELFTEST, lib, rt, 2)
+        good = "DRIVER DONE" in r.stdout and (len(s) > 0) == bool(expect)
+        print(f"self-test {which:<7} reports: {len(s)}  {'ok' if good else 'UNEXPECTED'}")
+        ok = ok and good
+    for threads in (2, 3):
+        r, s = run(asan_check.DRIVER, lib, rt, threads)
+        done = "DRIVER DONE" in r.stdout
+        print(f"library driver, {threads} workers: {'finished' if done else 'FAILED (exit %d)' % r.returncode}, {len(s)} distinct race sites")
+        for pair in s:
+            print("   ", "  <->  ".join(pair))
+        if not done:
+            sys.stdout.write(r.stderr[-3000:])
+        ok = ok and done and not s
+    print("TSAN CLEAN" if ok else "TSAN REPORTS OR FAILURE")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

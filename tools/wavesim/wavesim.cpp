@@ -52,6 +52,30 @@ extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const voi
 #define WAVESIM_ASAN_FINISH(save, bottom_old, size_old) ((void)0)
 #endif
 
+// ThreadSanitizer build (build_sim.py --tsan): the KERNEL translation units are instrumented, this file is not.  Every lane
+// is a TSan fiber; switches carry no synchronisation, so the only happens-before edges inside a launch are the ones the
+// hardware gives: a workgroup barrier orders the workgroup's lanes, a wave-level operation (or CACO_WAVE_LDS_SYNC) orders the
+// lanes of that wave, the end of a workgroup orders it before the next workgroup on the same worker.  Two lanes of different
+// waves that touch the same LDS bytes with no barrier in between, or two workgroups that touch the same global bytes, are
+// reported as a data race with both source lines.
+#ifdef WAVESIM_TSAN
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
+}
+#define TSAN_SWITCH(f) __tsan_switch_to_fiber(f, 1u /* no_sync */)
+#define TSAN_ACQUIRE(a) __tsan_acquire(a)
+#define TSAN_RELEASE(a) __tsan_release(a)
+#else
+#define TSAN_SWITCH(f) ((void)0)
+#define TSAN_ACQUIRE(a) ((void)0)
+#define TSAN_RELEASE(a) ((void)0)
+#endif
+
 namespace wavesim {
 
 WAVESIM_TLS Lane* cur = nullptr;
@@ -90,6 +114,11 @@ struct Worker {                 // per OS thread: fiber stacks, lane / wave reco
   const std::function<void()>* body = nullptr;
   int bar_gen = 0;                              // completed workgroup barriers of the running block
   int bar_or[2] = {0, 0};                       // __syncthreads_or accumulators, by barrier parity
+  void* main_fiber = nullptr;                   // TSan: the scheduler's own context and one fiber per lane of the running block
+  void** fibers = nullptr;
+  char tag_block = 0, tag_epoch[2] = {0, 0};    // TSan: addresses the barrier / workgroup-boundary edges hang on
+  unsigned serial = 0;                          // workgroups this worker has run (parity picks the epoch tag)
+  char tag_wave[MAX_THREADS / 64] = {};
   ~Worker() {
     if (stacks) munmap(stacks, STACK_BYTES * MAX_THREADS);
     free(lanes);
@@ -116,11 +145,15 @@ WAVESIM_TLS Worker* tl_w = &g_workers[0];
 void lane_entry() {
   Worker& W = *tl_w;
   WAVESIM_ASAN_FINISH(nullptr, &W.main_stack_bottom, &W.main_stack_size);
+  TSAN_ACQUIRE(&W.tag_epoch[(W.serial ^ 1) & 1]);      // after the PREVIOUS workgroup on this worker (its LDS, stacks and statics are
+                                                       // reused), never after a lane of this one that happened to finish first
   (*W.body)();
   Lane* L = cur;
   L->state = 3;
   while (L->vm_count) vm_retire_one(L);     // outstanding DMA still lands (nobody can observe it any more)
+  TSAN_RELEASE(&W.tag_epoch[W.serial & 1]);
   WAVESIM_ASAN_START(nullptr, W.main_stack_bottom, W.main_stack_size);      // null: this fiber never comes back
+  TSAN_SWITCH(W.main_fiber);
   wavesim_switch(&L->sp, W.main_sp);
   fail("resumed a finished lane");
 }
@@ -131,6 +164,7 @@ void yield_to_scheduler() {
   void* fake = nullptr;
   (void)fake;
   WAVESIM_ASAN_START(&fake, W.main_stack_bottom, W.main_stack_size);
+  TSAN_SWITCH(W.main_fiber);
   wavesim_switch(&L->sp, W.main_sp);
   WAVESIM_ASAN_FINISH(fake, nullptr, nullptr);
 }
@@ -175,6 +209,13 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
   }
   W.bar_gen = 0;
   W.bar_or[0] = W.bar_or[1] = 0;
+#ifdef WAVESIM_TSAN
+  W.main_fiber = __tsan_get_current_fiber();
+  if (!W.fibers) W.fibers = (void**)calloc(MAX_THREADS, sizeof(void*));
+  for (int t = 0; t < nthreads; ++t) W.fibers[t] = __tsan_create_fiber(0);
+  ++W.serial;
+  TSAN_RELEASE(&W.tag_epoch[(W.serial ^ 1) & 1]);      // the launching side's writes (and the LDS fill above) come before every lane
+#endif
   unsigned seed = 1;
   const int mode = order_mode(&seed);
   seed = seed * 2654435761u + bidx.x * 97u + bidx.y * 7919u + bidx.z * 104729u;
@@ -200,6 +241,9 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
             void* fake = nullptr;
             (void)fake;
             WAVESIM_ASAN_START(&fake, L->stack, STACK_BYTES);
+#ifdef WAVESIM_TSAN
+            TSAN_SWITCH(W.fibers[L - W.lanes]);
+#endif
             wavesim_switch(&W.main_sp, L->sp);
             WAVESIM_ASAN_FINISH(fake, nullptr, nullptr);
             progress = true;
@@ -235,6 +279,10 @@ void run_block(idx3 bidx, idx3 bdim, idx3 gdim, const std::function<void()>& bod
     if (!progress && live > 0) fail("deadlock in block (%u,%u,%u)", bidx.x, bidx.y, bidx.z);
   }
   cur = nullptr;
+#ifdef WAVESIM_TSAN
+  TSAN_ACQUIRE(&W.tag_epoch[W.serial & 1]);     // the worker thread (and, through its join, the host) sees what the lanes wrote
+  for (int t = 0; t < nthreads; ++t) __tsan_destroy_fiber(W.fibers[t]);
+#endif
 }
 
 }  // namespace
@@ -243,12 +291,17 @@ void wave_rendezvous(const void* site) {
   Lane* L = cur;
   L->site = site;
   L->state = 1;
+  [[maybe_unused]] char* tag = &tl_w->tag_wave[L->wave - tl_w->waves];
+  TSAN_RELEASE(tag);
   yield_to_scheduler();
+  TSAN_ACQUIRE(tag);
 }
 
 void block_barrier() {
   cur->state = 2;
+  TSAN_RELEASE(&tl_w->tag_block);
   yield_to_scheduler();
+  TSAN_ACQUIRE(&tl_w->tag_block);
 }
 
 int block_barrier_or(int pred) {
@@ -304,8 +357,16 @@ void launch(idx3 grid, idx3 block, size_t lds_bytes, const std::function<void()>
   std::atomic<long> next{0};
   auto work = [&](int slot) {
     tl_w = &g_workers[slot];
+#ifdef WAVESIM_TSAN
+    long mine = slot > 0 ? slot - 1 : 0;        // static round-robin: neighbouring workgroups always run on different workers, and
+#endif                                           // workgroups of different workers are never ordered (those of one worker are)
     for (;;) {
+#ifdef WAVESIM_TSAN
+      const long b = mine;
+      mine += nthr > 1 ? nthr : 1;
+#else
       const long b = next.fetch_add(1);
+#endif
       if (b >= nblocks) break;
       idx3 bi;
       bi.x = (unsigned)(b % grid.x);

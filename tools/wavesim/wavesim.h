@@ -92,6 +92,9 @@ inline const unsigned char* xget(int lane) { return cur->wave->x[(cur->wave->gen
 inline bool xlive(int lane) { return (cur->wave->active[(cur->wave->gen - 1) & 1] >> lane) & 1ull; }
 
 // vector-memory queue
+#ifdef WAVESIM_TSAN
+extern "C" void __tsan_write_range(void* addr, unsigned long size);
+#endif
 inline void vm_retire_one(Lane* L) {
   VmOp& o = L->vm[L->vm_head];
   if (o.bytes > 0) memcpy(o.lds, o.data, (size_t)o.bytes);
@@ -105,6 +108,11 @@ inline void vm_push(char* lds, const void* data, int bytes) {
   o.lds = lds;
   o.bytes = 0;
   if (bytes > 0) {
+#ifdef WAVESIM_TSAN
+    // the hardware may write the bytes at any moment between issue and the covering wait: the race detector is told about a
+    // write at both ends (a wave still reading this buffer when another wave issues its refill is a WAR hazard)
+    __tsan_write_range(lds, (unsigned long)bytes);
+#endif
     if (dma_late) { o.bytes = bytes; memcpy(o.data, data, (size_t)bytes); }
     else memcpy(lds, data, (size_t)bytes);
   }

@@ -40,6 +40,38 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(DEV)
 
 
+def test_gemm_every_tile_kernel_gives_the_same_bits(lib):
+    """Same case as tests/test_wavesim.py: every kernel family a batch size can select produces identical bits (same K order,
+    same epilogue rounding), which is what makes a clip's embedding independent of its batch mates."""
+    M, N, K = 600, 768, 768
+    a = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    bias, x = _rand((N,), 13), _rand((M, N), 14)
+    tiles = (128, 2256, 8256, 4256, 4128)
+    try:
+        for act in (0, 1, 2):
+            outs = []
+            for tile in tiles:
+                lib.caco_set_gemm_tile(tile)
+                o = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+                _lib.check(lib.caco_op_gemm_bf16(_p(a), _p(w), _p(bias), M, N, K, act, _p(o), _st()))
+                torch.cuda.synchronize()
+                outs.append(o.view(torch.int16))
+            for tile, o in zip(tiles[1:], outs[1:]):
+                assert torch.equal(o, outs[0]), f"act {act}: tile {tile} differs from tile 128 in {(o != outs[0]).sum().item()} elements"
+        outs = []
+        for tile in tiles:
+            lib.caco_set_gemm_tile(tile)
+            o = torch.zeros(M, N, device=DEV)
+            _lib.check(lib.caco_op_gemm_bf16_f32out(_p(a), _p(w), _p(bias), _p(x), M, N, K, _p(o), _st()))
+            torch.cuda.synchronize()
+            outs.append(o)
+        for tile, o in zip(tiles[1:], outs[1:]):
+            assert torch.equal(o, outs[0]), f"fp32 residual: tile {tile} differs from tile 128"
+    finally:
+        lib.caco_set_gemm_tile(256)
+
+
 @pytest.mark.parametrize("tile", [128, 256, 2256, 8256, 4256, 4128])       # 4256 / 4128: round-3 experiments (gemm_w4q.hip, gemm_w4h.hip)
 @pytest.mark.parametrize("M,N,K,act", [(1000, 768, 256, 0), (4096, 1536, 768, 0), (2500, 3072, 768, 1),
                                        (2048, 768, 3072, 0), (8192, 3072, 768, 2), (300, 256, 768, 0),

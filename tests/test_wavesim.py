@@ -72,6 +72,37 @@ def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(256)
 
 
+def test_gemm_every_tile_kernel_gives_the_same_bits(sim):
+    """What makes a clip's embedding independent of its batch mates (tests/test_gpu_model.py::test_odd_batch_sizes_...):
+    the kernel families a batch size selects - 128 x 128, x, w8, w4q, w4h - accumulate K in the same order and round the
+    same way in their epilogues (the w8 family writes SiLU as exp2(x * -log2 e) by hand, the others call __expf)."""
+    M, N, K = 600, 768, 768
+    a = _rand((M, K), 11).bfloat16()
+    w = _rand((N, K), 12, 1.0 / math.sqrt(K)).bfloat16()
+    bias, x = _rand((N,), 13), _rand((M, N), 14)
+    tiles = (128, 2256, 8256, 4256, 4128)
+    try:
+        for act in (0, 1, 2):
+            outs = []
+            for tile in tiles:
+                sim.caco_set_gemm_tile(tile)
+                o = torch.zeros(M, N, dtype=torch.bfloat16)
+                simlib.check(sim.caco_op_gemm_bf16(P(a), P(w), P(bias), M, N, K, act, P(o), None))
+                outs.append(o.view(torch.int16))
+            for tile, o in zip(tiles[1:], outs[1:]):
+                assert torch.equal(o, outs[0]), f"act {act}: tile {tile} differs from tile 128 in {(o != outs[0]).sum().item()} elements"
+        outs = []
+        for tile in tiles:
+            sim.caco_set_gemm_tile(tile)
+            o = torch.zeros(M, N)
+            simlib.check(sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(x), M, N, K, P(o), None))
+            outs.append(o)
+        for tile, o in zip(tiles[1:], outs[1:]):
+            assert torch.equal(o, outs[0]), f"fp32 residual: tile {tile} differs from tile 128"
+    finally:
+        sim.caco_set_gemm_tile(256)
+
+
 @pytest.mark.parametrize("tile", [8256, 4256, 4128], ids=["w8", "w4q", "w4h"])
 @pytest.mark.parametrize("kind", ["f32r", "bf16", "silu"])
 def test_gemm_w8_persistent_multi_tile_pipeline(sim, kind, tile):

@@ -33,6 +33,44 @@ print("DRIVER DONE")
 '''
 
 
+# second driver: the persistent GEMM kernels with several tiles per workgroup (WAVESIM_CUS = 3: LDS stages are reused from tile to
+# tile), the audio tower's attention shape (two query blocks per wave) with a masked tail
+DRIVER2 = r'''
+import ctypes as C, math, os, sys
+import numpy as np
+sys.path.insert(0, REPO)
+from cacophony_amd import _lib, config as Cfg, synth
+lib = C.CDLL(LIB)
+for name, (res, args) in _lib._SIGNATURES.items():
+    fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+P = lambda a: C.c_void_p(0 if a is None else a.ctypes.data)
+def chk(rc, what=""):
+    assert rc == 0, (what, lib.caco_last_error())
+def bf16(x):
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+rng = np.random.default_rng(1)
+# persistent kernels with several tiles per workgroup (WAVESIM_CUS = 3): LDS stages are reused from tile to tile
+for tile in (2256, 8256, 4256, 4128):
+    lib.caco_set_gemm_tile(tile)
+    for (M, N, K, act) in ((2100, 768, 512, 1), (1300, 1536, 256, 0)):
+        a, w, b = bf16(rng.standard_normal((M, K))), bf16(rng.standard_normal((N, K)) / math.sqrt(K)), rng.standard_normal(N).astype(np.float32)
+        out = np.zeros((M, N), np.uint16)
+        chk(lib.caco_op_gemm_bf16(P(a), P(w), P(b), M, N, K, act, P(out), None), "gemm")
+        x = rng.standard_normal((M, N)).astype(np.float32)
+        chk(lib.caco_op_gemm_bf16_f32out(P(a), P(w), P(b), P(x), M, N, K, P(x), None), "gemm f32")
+lib.caco_set_gemm_tile(256)
+# the audio tower's attention shape (two query blocks per wave), and a masked tail
+for (B, S, heads, hd, causal) in ((2, 500, 2, 96, 0), (1, 300, 2, 64, 0)):
+    H = heads * hd
+    qkv = bf16(rng.standard_normal((B, S, 3 * H)))
+    mask = np.ones((B, S), np.float32); mask[-1, S - 7:] = 0
+    out = np.zeros((B, S, H), np.uint16)
+    chk(lib.caco_op_attention(P(qkv), 3 * H, H, 2 * H, P(mask), B, S, heads, hd, causal, P(out), None), "attention")
+print("DRIVER DONE")
+'''
+
+
 def sites(err):
     """Unique (kernel source line, kernel source line) pairs of the reports."""
     out = set()
@@ -42,8 +80,8 @@ def sites(err):
     return sorted(out)
 
 
-def run(code, lib, rt, threads):
-    env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", WAVESIM_THREADS=str(threads),
+def run(code, lib, rt, threads, **extra):
+    env = dict(os.environ, **extra, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", WAVESIM_THREADS=str(threads),
                OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\nLIB = {lib!r}\n" + code], env=env, capture_output=True, text=True)
     return r, sites(r.stderr)
@@ -71,6 +109,12 @@ def main():
         if not done:
             sys.stdout.write(r.stderr[-3000:])
         ok = ok and done and not s
+    r, s = run(DRIVER2, lib, rt, 3, WAVESIM_CUS="3")
+    done = "DRIVER DONE" in r.stdout
+    print(f"multi-tile driver (3 CUs, 3 workers): {'finished' if done else 'FAILED (exit %d)' % r.returncode}, {len(s)} distinct race sites")
+    for pair in s:
+        print("   ", "  <->  ".join(pair))
+    ok = ok and done and not s
     print("TSAN CLEAN" if ok else "TSAN REPORTS OR FAILURE")
     return 0 if ok else 1
 

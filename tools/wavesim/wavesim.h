@@ -198,7 +198,9 @@ template <typename A, typename B>
 static inline auto min(A a, B b) -> decltype(a + b) { return a < b ? a : b; }
 template <typename A, typename B>
 static inline auto max(A a, B b) -> decltype(a + b) { return a > b ? a : b; }
-#define __expf(x) expf(x)
+// __expf lowers to v_mul_f32 (by log2 e) + v_exp_f32 on the device: the same two roundings here, so that a kernel that writes
+// exp2(x * log2e) by hand agrees bit for bit with one that calls __expf, as it does on the hardware
+#define __expf(x) exp2f((x) * 1.4426950408889634f)
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

@@ -36,7 +36,8 @@ def load() -> C.CDLL:
         return _sim
     sys.path.insert(0, os.path.join(REPO, "tools", "wavesim"))
     import build_sim
-    path = build_sim.build(verbose=False)
+    # CACO_SIM_LIB: a sanitizer build of the same library (tools/wavesim/tsan_check.py --pytest preloads the runtime)
+    path = os.environ.get("CACO_SIM_LIB") or build_sim.build(verbose=False)
     lib = C.CDLL(path)
     for name, (res, args) in _lib._SIGNATURES.items():
         fn = getattr(lib, name)

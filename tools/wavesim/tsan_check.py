@@ -7,6 +7,9 @@ round-robin over WAVESIM_THREADS workers; those of one worker are ordered, so th
 
     python tools/wavesim/tsan_check.py            # self-test (a planted LDS race and a planted global race must be reported,
                                                   # their barrier-ed twins must not), then the driver of asan_check.py
+    python tools/wavesim/tsan_check.py --pytest [pytest arguments]
+                                                  # tests/test_wavesim.py (every kernel and the model paths: decoders, MAE,
+                                                  # poolers, ...) with the TSan build loaded through CACO_SIM_LIB
 
 Exit status 0 and "TSAN CLEAN" on the last line = self-test behaved and the library produced no report."""
 import os
@@ -94,6 +97,18 @@ def main():
     lib = build_sim.build(tsan=True, lib=os.path.join(HERE, "libcaco_sim_tsan.so"), verbose=False,
                           extra=[os.path.join(HERE, "selftest", "race_selftest.hip")])
     rt = subprocess.run([build_sim.CXX, "-print-file-name=libclang_rt.tsan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if "--pytest" in sys.argv:
+        args = sys.argv[sys.argv.index("--pytest") + 1:] or ["tests/test_wavesim.py", "-q"]
+        env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", CACO_SIM_LIB=lib,
+                   WAVESIM_THREADS="3", OMP_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", *args], cwd=REPO, env=env, capture_output=True, text=True)
+        sys.stdout.write(r.stdout[-1500:])
+        s = sites(r.stderr)
+        print(f"pytest under ThreadSanitizer: exit {r.returncode}, {len(s)} distinct race sites")
+        for pair in s:
+            print("   ", "  <->  ".join(pair))
+        print("TSAN CLEAN" if (r.returncode == 0 and not s) else "TSAN REPORTS OR FAILURE")
+        return 0 if (r.returncode == 0 and not s) else 1
     ok = True
     for which, expect in (("clean", 0), ("lds", 1), ("global", 1)):
         r, s = run(f"WHICH = {which!r}\n" + SELFTEST, lib, rt, 2)

@@ -11,12 +11,64 @@ if REPO not in sys.path:
 GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
 
 if os.environ.get("CACO_GPU_ON_SIM") == "1":          # opt-in: the `-m gpu` test bodies on tools/wavesim (tests/fakecuda.py)
+    if os.path.exists("/dev/kfd"):
+        raise pytest.UsageError("CACO_GPU_ON_SIM=1 on a box with a real GPU device node: the -m gpu cases must run on "
+                                "cacophony_amd/libcaco_hip.so here, not on the simulator build")
     from tests import fakecuda
     fakecuda.install()
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+    config.addinivalue_line("markers", "experimental: exercises a never-default kernel or an opt-in CACO_* switch; "
+                            "collected after every default-path case so that `-x` cannot hide the product behind it")
+
+
+EXPERIMENTAL_TILES = (4256, 4128)          # forced tile codes of kernels no default dispatch selects
+
+
+def _is_experimental(item):
+    if item.get_closest_marker("experimental") is not None:
+        return True
+    cs = getattr(item, "callspec", None)
+    return cs is not None and (cs.params.get("tile") in EXPERIMENTAL_TILES or cs.params.get("ln_fold") == 1)
+
+
+def pytest_collection_modifyitems(config, items):
+    """Default-path cases first (file order kept), experimental ones last: the driver runs `pytest -x`."""
+    items.sort(key=lambda it: 1 if _is_experimental(it) else 0)      # list.sort is stable
+
+
+def _mapped_caco_libraries():
+    libs = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libcaco" in os.path.basename(path) and path not in libs:
+                    libs.append(path)
+    except OSError:
+        pass
+    return libs
+
+
+def pytest_report_header(config):
+    from cacophony_amd import _lib
+    return f"caco library: {_lib.LIB_PATH} (real GPU device node: {os.path.exists('/dev/kfd')})"
+
+
+@pytest.fixture(autouse=True)
+def _gpu_cases_run_on_the_product_library(request):
+    """A `-m gpu` case on a box with a real device must map cacophony_amd/libcaco_hip.so and nothing else named
+    libcaco*: neither the simulator build (tools/wavesim) nor a compile-time variant may stand in for the product."""
+    yield
+    if request.node.get_closest_marker("gpu") is None or os.environ.get("CACO_GPU_ON_SIM") == "1":
+        return
+    product = os.path.realpath(os.path.join(REPO, "cacophony_amd", "libcaco_hip.so"))
+    mapped = [os.path.realpath(p) for p in _mapped_caco_libraries()]
+    if os.environ.get("CACO_ALLOW_VARIANT_LIB") == "1":          # tools/ab_bench.sh style runs of a variant build
+        return
+    assert mapped and all(m == product for m in mapped), f"-m gpu case ran with {mapped or 'no caco library'}, expected {product}"
 
 
 def load_golden(name):

@@ -115,6 +115,7 @@ def test_full_config_matches_reference_golden(full_model, ln_fold):
     assert _centred_cos(t_n.cpu().numpy(), g["text_emb_norm"]).min() > CENTRED_TOL
 
 
+@pytest.mark.experimental
 def test_ln_folded_stack_equals_ln_pass_stack(full_model):
     """The folded form is an algebraic rewrite: hidden states of the two forms agree far inside the parity budget,
     also for ragged batch sizes (M not a multiple of the 256-row tile) and large-mean rows."""
@@ -497,6 +498,7 @@ def test_unindexed_device_and_host_inputs_to_encode_pairs(tiny_state):
         m.encode_pairs(torch.from_numpy(wav), ids, tmask, lengths=[32000])
 
 
+@pytest.mark.experimental
 def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
     """CACO_POS_FUSE=1: the positional embedding as a gathered residual of the patch-embed GEMM instead of a separate pass
     (same case as tests/test_wavesim.py, at a batch the persistent kernel is the default for).  Same hidden states up to fp32
@@ -519,6 +521,7 @@ def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
     assert cosine_rows(outs["1"][0], outs["0"][0]).min() > 0.9999
 
 
+@pytest.mark.experimental
 def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch):
     """Every round-3 opt-in at once (fused positional embedding, short-sequence attention kernel) against the reference's
     own outputs, full and tiny configuration."""
@@ -534,6 +537,7 @@ def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch
         full_model._lib.caco_set_gemm_tile(256)
 
 
+@pytest.mark.experimental
 def test_final_layernorm_inside_the_pooler(full_model, monkeypatch):
     """CACO_POOL_FUSE=1 (same case as tests/test_wavesim.py): encode_audio's final LayerNorm applied inside the pooling kernel."""
     wav = synth.make_waveforms(6, start=11)
@@ -563,6 +567,7 @@ def test_audio_pooler_head_counts_match_reference(tiny_state, heads):
     assert rel_l2(emb, ref) < 0.5 * rel_l2(emb, other)
 
 
+@pytest.mark.experimental
 def test_pingpong_traversal_changes_nothing_but_the_order(full_model, monkeypatch):
     """CACO_PINGPONG=1 (same case as tests/test_wavesim.py, at a batch the persistent kernels are the default for): pure
     re-ordering of independent work, so the embeddings are bitwise those of the default order."""

@@ -40,6 +40,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(DEV)
 
 
+@pytest.mark.experimental
 def test_gemm_every_tile_kernel_gives_the_same_bits(lib):
     """Same case as tests/test_wavesim.py: every kernel family a batch size can select produces identical bits (same K order,
     same epilogue rounding), which is what makes a clip's embedding independent of its batch mates."""
@@ -350,6 +351,7 @@ def test_mel_lengths_bound_the_sample_fetch():
         assert np.abs(p["audio_patches"][i, :nv].cpu().numpy() - ref["audio_patches"][0, :nv]).max() < 1e-3
 
 
+@pytest.mark.experimental
 @pytest.mark.parametrize("B,Sq,S,heads,causal,valid", [
     (256, 32, 32, 12, 1, None), (5, 32, 32, 3, 0, [32, 7, 20, 32, 1]), (2, 64, 64, 12, 1, [64, 33]), (2, 37, 37, 2, 1, [37, 5]),
     (2, 20, 50, 12, 0, [50, 33]), (3, 1, 64, 12, 0, [64, 2, 1]), (1, 33, 33, 1, 0, [0])])

@@ -1,14 +1,14 @@
 #!/bin/bash
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
-#   gpurun --timeout 1800 -- 'bash tools/r3_gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
-#   bash tools/r3_gpu_session.sh all                                    everything in one call (~60 min)
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
+#   bash tools/gpu_session.sh all                                    everything in one call (~60 min)
 # 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
 # 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | CACO_POOL_FUSE=1 | all three | CACO_W_NGROUP=0
 # 3. rocprofv3 kernel stats of the default build and of the build with both switches on
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}
-OUT=gpurun_out/r3_v0
+OUT=${OUT:-gpurun_out/r4_v0}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
@@ -20,8 +20,8 @@ tail -3 "$OUT/pytest_gpu.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
-bash tools/profile_bench.sh r3_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
-cp gpurun_out/prof_r3_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+bash tools/profile_bench.sh r4_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
+cp gpurun_out/prof_r4_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 fi
 ab() {   # name, env assignments...
   local name=$1; shift

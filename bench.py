@@ -272,6 +272,19 @@ def _timeit(fn, n, sync):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+SWITCH_NAMES = ("CACO_PINGPONG", "CACO_POS_FUSE", "CACO_POOL_FUSE", "CACO_ATTN_SMALL", "CACO_ATTN_ROWS", "CACO_W_NGROUP",
+                "CACO_W8_MIN_TILES", "CACO_W4H_MAX_TILES")
+
+
+def _switches_in_force(lib):
+    """What the library itself reports (caco_get_switch), plus the LayerNorm-fold default: an A/B line says what it measured."""
+    if lib is None:
+        return None
+    d = {n: int(lib.caco_get_switch(n.encode())) for n in SWITCH_NAMES}
+    d["CACO_LN_FOLD"] = int(lib.caco_set_ln_fold(-99))
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,14 +391,22 @@ def main():
                 ent.update(bound="hbm", achieved_gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
             stages[name] = ent
         dom = stages.get("audio.gemm_fc1")
+        # HBM bytes of one fc1 launch: a committed TCC-counter measurement (tools/pmc_hbm.sh), quoted ONLY when it was taken
+        # with the tile order this run uses (its "w_ngroup" field; files without the field predate the n-tile groups and
+        # describe one group).  Anything else would pair this run's time with another schedule's bytes.
         traffic, traffic_source = None, None
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")))
-            if cands:
-                traffic = int(json.load(open(cands[-1]))["hbm_bytes"])
-                traffic_source = (os.path.relpath(cands[-1], REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 launch "
-                                  "(tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
+            ngroup_now = int(lib.caco_get_switch(b"CACO_W_NGROUP"))
+            for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True):
+                rec = json.load(open(cand))
+                if int(rec.get("w_ngroup", 0)) == ngroup_now:
+                    traffic = int(rec["hbm_bytes"])
+                    traffic_source = (os.path.relpath(cand, REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 "
+                                      "launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
+                    break
+            else:
+                traffic_source = f"no committed hbm_traffic.json was measured with the tile order in force (CACO_W_NGROUP = {ngroup_now})"
         except Exception:
             traffic = None
         # algorithmic bytes of one fc1 launch: A [M,768] bf16 in + W [3072,768] bf16 in + out [M,3072] bf16
@@ -446,7 +467,7 @@ def main():
                        "caption_tokens": TEXT_LEN, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)",
                        "gemm_tile": int(lib.caco_set_gemm_tile(0)) if lib is not None else None,
                        # run-time switches in force: an A/B line says what it measured
-                       "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("CACO_") and k != "CACO_BENCH_DRYRUN"}},
+                       "switches": _switches_in_force(lib)},
             "roofline": roofline, "cpu_baseline": cpu, "extra_configs": extra, "stages": stages, "outputs_finite": finite,
         }
         if DRYRUN:

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "caco_mae_forward": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "caco_workspace_bytes": (_i64, [_vp]),
     "caco_set_gemm_tile": (_i32, [_i32]),
+    "caco_set_switch": (C.c_int, [C.c_char_p, _i32]),
+    "caco_get_switch": (_i32, [C.c_char_p]),
     "caco_set_ln_fold": (_i32, [_i32]),
     "caco_model_set_ln_fold": (_i32, [_vp, _i32]),
     "caco_profile_enable": (C.c_int, [_i32]),
@@ -113,6 +115,24 @@ def load() -> C.CDLL:
         raise RuntimeError(f"caco_config is {lib.caco_config_size()} bytes in {LIB_PATH} but {C.sizeof(CacoConfigC)} in this binding")
     _lib = lib
     return lib
+
+
+class switch:
+    """Context manager for tests / A-B runs: `with switch("CACO_POS_FUSE", 1): ...` sets a run-time switch of the library
+    (caco_set_switch) and restores its previous value on exit."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        lib = load()
+        self.prev = lib.caco_get_switch(self.name)
+        check(lib.caco_set_switch(self.name, self.value), "caco_set_switch")
+        return self
+
+    def __exit__(self, *exc):
+        load().caco_set_switch(self.name, self.prev)
+        return False
 
 
 def last_error() -> str:

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <climits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,6 +33,30 @@ int check_hip(hipError_t e, const char* what) {
   if (e == hipSuccess) return CACO_OK;
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return CACO_ERR_HIP;
+}
+
+// run-time switches (kernels.h): environment read once per switch, then caco_set_switch only
+struct SwitchSlot {
+  const char* name;
+  int def;
+  std::atomic<int> value;
+};
+static SwitchSlot g_switches[SW_COUNT] = {
+    {"CACO_PINGPONG", 0, {INT_MIN}},     {"CACO_POS_FUSE", 0, {INT_MIN}},  {"CACO_POOL_FUSE", 0, {INT_MIN}},
+    {"CACO_ATTN_SMALL", 0, {INT_MIN}},   {"CACO_ATTN_ROWS", 64, {INT_MIN}}, {"CACO_W_NGROUP", -1, {INT_MIN}},
+    {"CACO_W8_MIN_TILES", 128, {INT_MIN}}, {"CACO_W4H_MAX_TILES", 0, {INT_MIN}},
+};
+int sw(Switch s) {
+  SwitchSlot& slot = g_switches[s];
+  int v = slot.value.load(std::memory_order_relaxed);
+  if (v == INT_MIN) {                      // first use in this process: the environment's value, or the default
+    const char* e = getenv(slot.name);
+    v = e && *e ? atoi(e) : slot.def;
+    if (v == INT_MIN) v = slot.def;
+    int expect = INT_MIN;
+    if (!slot.value.compare_exchange_strong(expect, v, std::memory_order_relaxed)) v = expect;
+  }
+  return v;
 }
 
 // per (kernel, device): dynamic-LDS attribute set once; per device: CU count (kernels.h)
@@ -486,12 +512,8 @@ int linear_bf16(const Lin& L, const bf16_t* a, int64_t M, int act, bf16_t* out, 
 // In ISOLATION (the same GEMM launched back to back, tools/gemm_ldc_bench.py) the 4608-byte pitch of 3H = 2304 is
 // pathological for the 128 000-row QKV GEMM's stores: 496 us at 2304, 425 at 2432, 401 at 2560, 398 at 3072, while every
 // other pitch on the path (1536, 3072, 6144 bytes) is insensitive.  Inside the pipeline the GEMM itself does not care
-// (5.04 ms per step either way, A/B on one box); the attention kernel reading the buffer gains 1.5 %.  CACO_QKV_PAD=0
-// turns it off.
-inline int qkv_ld(int H) {
-  static const int pad = getenv("CACO_QKV_PAD") ? atoi(getenv("CACO_QKV_PAD")) : 1;
-  return pad ? (3 * H + 511) / 512 * 512 : 3 * H;
-}
+// (5.04 ms per step either way, A/B on one box); the attention kernel reading the buffer gains 1.5 %.
+inline int qkv_ld(int H) { return (3 * H + 511) / 512 * 512; }
 int linear_f32(const Lin& L, const bf16_t* a, int64_t M, const float* resid, float* out, hipStream_t st, int order = 0) {
   GemmArgs g{a, L.w, L.b, resid, out, M, L.out, L.in, L.out};
   set_order(g, order);
@@ -541,15 +563,12 @@ int linear_resid_stats(const Lin& L, const bf16_t* a, int64_t M, float* x, bf16_
 // LayerNorm consumes the raw rows (bf16 copy xb) with gamma-scaled weights and applies mean / rstd per row in its
 // epilogue; the GEMM that produces new residual rows (out-proj, fc2) also writes xb and per-row partial sums, which a
 // tiny kernel turns into (mean, rstd).  Saves 590 MB of HBM traffic and a launch per LayerNorm.
-// CACO_PINGPONG=1 (read at every call; round 3, untimed): consecutive kernels of a layer walk the rows in OPPOSITE directions
+// CACO_PINGPONG=1 (switch SW_PINGPONG; round 3, untimed): consecutive kernels of a layer walk the rows in OPPOSITE directions
 // inside the 8 row ranges the XCDs own (LayerNorm: layernorm_ranges_kernel; attention: contiguous clips per XCD; GEMMs: one
 // n-tile group, reversed tile list).  Every kernel then starts on the rows its producer wrote last - the part of the
 // producer's output that is still in the 256 MiB Infinity Cache - instead of on the rows that were written first and have
 // been evicted by the rest of the same output (fc1's output alone is 780 MB).  `kdir` counts kernels; its parity is the direction.
-bool pingpong_enabled() {
-  const char* e = getenv("CACO_PINGPONG");
-  return e && atoi(e) != 0;
-}
+bool pingpong_enabled() { return sw(SW_PINGPONG) != 0; }
 
 int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const Arena& A, const AudioWs& w,
                      const float* mask, int batch, int seq, int heads, float eps, hipStream_t st, int* kdir = nullptr) {
@@ -594,17 +613,11 @@ int run_audio_layers(caco_model* m, const std::vector<AudioLayer>& layers, const
   return CACO_OK;
 }
 
-// CACO_POS_FUSE=1 (read at every call; opt-in until timed on hardware): positional embedding inside the patch-embed GEMM
-bool pos_fuse_enabled() {
-  const char* e = getenv("CACO_POS_FUSE");
-  return e && atoi(e) != 0;
-}
+// CACO_POS_FUSE=1 (switch SW_POS_FUSE; opt-in until timed on hardware): positional embedding inside the patch-embed GEMM
+bool pos_fuse_enabled() { return sw(SW_POS_FUSE) != 0; }
 
-// CACO_POOL_FUSE=1 (read at every call; opt-in until timed): the audio tower's final LayerNorm inside the pooling kernel
-bool pool_fuse_enabled() {
-  const char* e = getenv("CACO_POOL_FUSE");
-  return e && atoi(e) != 0;
-}
+// CACO_POOL_FUSE=1 (switch SW_POOL_FUSE; opt-in until timed): the audio tower's final LayerNorm inside the pooling kernel
+bool pool_fuse_enabled() { return sw(SW_POOL_FUSE) != 0; }
 
 // The model's weights, arenas and per-device kernel state live on ONE device: a call with another device current would
 // dereference foreign memory.  Reject it instead.
@@ -749,6 +762,23 @@ int64_t caco_workspace_bytes(const caco_model* m) {
   return n;
 }
 int32_t caco_set_gemm_tile(int32_t tile) { return set_gemm_tile_config(tile); }
+int caco_set_switch(const char* name, int32_t value) {
+  CACO_REQUIRE(name, "caco_set_switch: null name");
+  for (int i = 0; i < SW_COUNT; ++i)
+    if (!strcmp(name, g_switches[i].name)) {
+      sw((Switch)i);                               // settle the environment's initial value first, so that it cannot overwrite this one
+      g_switches[i].value.store(value, std::memory_order_relaxed);
+      return CACO_OK;
+    }
+  set_error("caco_set_switch: unknown switch '%s'", name);
+  return CACO_ERR_INVALID;
+}
+int32_t caco_get_switch(const char* name) {
+  if (name)
+    for (int i = 0; i < SW_COUNT; ++i)
+      if (!strcmp(name, g_switches[i].name)) return sw((Switch)i);
+  return INT32_MIN;
+}
 int32_t caco_set_ln_fold(int32_t mode) {
   if (mode >= -1 && mode <= 1) g_ln_fold = mode;
   return g_ln_fold;
@@ -1158,9 +1188,8 @@ int caco_encode_audio_ex(caco_model* m, const float* wav, const int64_t* lengths
   // (eval_caco_torch.py:573: 0.8 % of every GEMM / LayerNorm / attention row) - instead of on the padded window.
   // (caco_audio_forward keeps the caller's S: it returns hidden states for every position, padded ones included.)
   {
-    static const int keep_pad = getenv("CACO_KEEP_PAD") ? atoi(getenv("CACO_KEEP_PAD")) : 0;
     const int64_t full = ((n_samples + 159) / 160 / 16) * 8;
-    if (!keep_pad && full >= 1 && full < max_patches) max_patches = (int32_t)full;
+    if (full >= 1 && full < max_patches) max_patches = (int32_t)full;
   }
   // front-end outputs live in their own arena so that the forward's arena growth cannot move them
   const size_t n_tok = (size_t)batch * max_patches;

@@ -355,10 +355,7 @@ __global__ __launch_bounds__(NW * 64, QR == 1 ? 3 : 2) void attention_kernel(con
 }
 
 // experiment switch: CACO_ATTN_ROWS=32 keeps one query block per wave at every sequence length
-int attention_rows_per_wave() {
-  static const int v = [] { const char* e = getenv("CACO_ATTN_ROWS"); return e ? atoi(e) : 64; }();
-  return v;
-}
+int attention_rows_per_wave() { return sw(SW_ATTN_ROWS); }
 
 }  // namespace
 
@@ -381,12 +378,9 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   CACO_REQUIRE(heads <= 65535 && batch <= 65535, "attention: heads / batch exceed the grid limit");
   CACO_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "attention: row stride / operand offsets must be multiples of 8 elements");
   // short sequences (the text tower at T = 32): one wave per (clip, head, query block), attention_small.hip.  Opt-in
-  // (CACO_ATTN_SMALL=1, read at every call) until it has been timed and verified on hardware.
-  {
-    const char* e = getenv("CACO_ATTN_SMALL");
-    if (e && atoi(e) != 0 && attention_small_ok(seq_q, seq, head_dim))
-      return attention_small(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, causal, out, st, kv_batch_rows);
-  }
+  // (switch SW_ATTN_SMALL / CACO_ATTN_SMALL=1) until it has been timed and verified on hardware.
+  if (sw(SW_ATTN_SMALL) != 0 && attention_small_ok(seq_q, seq, head_dim))
+    return attention_small(q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, batch, seq, heads, causal, out, st, kv_batch_rows);
   const float scale_log2 = 1.4426950408889634f / sqrtf((float)head_dim);
   constexpr int NW = 4;
   // two query blocks per wave once the sequence fills the 256-row workgroups that makes; short sequences (text, decoder)

@@ -186,22 +186,25 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
     CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16: LayerNorm folding / a gathered residual need N %% 256 == 0 and K %% 64 == 0");
     return gemm_bf16_w8(p, epi, act, st);
   }
+  // the experimental 4-wave kernels carry the plain epilogues only (bias; bias + residual in fp32): anything else falls
+  // through to the default choice, as caco_hip.h promises for a forced kernel
+  const bool w4_ok = gemm_bf16_w8_ok(p, epi) && p.bias && ((epi == EPI_BF16 && !p.resid) || (epi == EPI_F32 && act == ACT_NONE));
   // forced kernels (tests, A/B runs): 8256 = persistent 256x256 (w8), 2256 = 256x128 two workgroups per CU
   if (cfg == 8256 && gemm_bf16_w8_ok(p, epi)) return gemm_bf16_w8(p, epi, act, st);
-  if (cfg == 4256 && gemm_bf16_w8_ok(p, epi) && p.bias) return gemm_bf16_w4q(p, epi, act, st);     // experiment: 4 waves of 128 x 128
-  if (cfg == 4128 && gemm_bf16_w8_ok(p, epi) && p.bias) return gemm_bf16_w4h(p, epi, act, st);     // experiment: 128 x 256 tiles (mid M)
+  if (cfg == 4256 && w4_ok) return gemm_bf16_w4q(p, epi, act, st);     // experiment: 4 waves of 128 x 128
+  if (cfg == 4128 && w4_ok) return gemm_bf16_w4h(p, epi, act, st);     // experiment: 128 x 256 tiles (mid M)
   if (cfg == 2256) return gemm_bf16_x(p, epi, act, st);
-  if (cfg == 256) {
+  if (cfg != 128) {      // 256, or a forced kernel that does not carry this shape / epilogue: the default choice
     // chip-filling shapes: the 256x256 persistent 8-wave pipelined kernel (gemm_w8.hip: most reuse per L2 byte) when every
     // CU gets >= 2 tiles, else the two-workgroups-per-CU 256x128 kernel when its grid covers the chip, else 128x128.
     // Threshold in 256x128-tile units.  128 also sends the text tower's M = 8192 GEMMs to w8: in isolation the 128x128
     // kernel is faster for its N = 768 shapes, but the text tower runs NEXT TO the audio tower and a few persistent
     // 160 KiB workgroups interleave with the audio GEMMs better than many small ones (step 32.2 -> 31.7 ms measured)
-    static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
+    const int w8_min = sw(SW_W8_MIN_TILES);
     // CACO_W4H_MAX_TILES=<n> (experiment, round 3): shapes with fewer than n 256 x 256 tiles - the text tower's N = 768 GEMMs
     // have 96 - take 128 x 256 tiles instead (gemm_w4h.hip)
-    static const int w4h_max = getenv("CACO_W4H_MAX_TILES") ? atoi(getenv("CACO_W4H_MAX_TILES")) : 0;
-    if (w4h_max > 0 && gemm_bf16_w8_ok(p, epi) && p.bias && tiles_x >= w8_min && ((p.M + 255) / 256) * (int64_t)(p.N / 256) < w4h_max)
+    const int w4h_max = sw(SW_W4H_MAX_TILES);
+    if (w4h_max > 0 && w4_ok && tiles_x >= w8_min && ((p.M + 255) / 256) * (int64_t)(p.N / 256) < w4h_max)
       return gemm_bf16_w4h(p, epi, act, st);
     if (gemm_bf16_w8_ok(p, epi) && tiles_x >= w8_min) return gemm_bf16_w8(p, epi, act, st);
     if (tiles_x >= 256) return gemm_bf16_x(p, epi, act, st);
@@ -217,16 +220,13 @@ bool gemm_bf16_picks_w8(const GemmArgs& p, int epi) {
   if (!gemm_bf16_w8_ok(p, epi) || p.K % BK != 0 || p.N % 128 != 0) return false;
   if (cfg == 8256) return true;
   if (cfg != 256) return false;
-  static const int w8_min = getenv("CACO_W8_MIN_TILES") ? atoi(getenv("CACO_W8_MIN_TILES")) : 128;
+  const int w8_min = sw(SW_W8_MIN_TILES);
   return ((p.M + 255) / 256) * (int64_t)(p.N / 128) >= w8_min;
 }
 
 static int g_tile_cfg = -1;
 int gemm_tile_config() {
-  if (g_tile_cfg < 0) {
-    const char* e = getenv("CACO_GEMM_TILE");
-    g_tile_cfg = (e && atoi(e) == 128) ? 128 : 256;
-  }
+  if (g_tile_cfg < 0) g_tile_cfg = 256;
   return g_tile_cfg;
 }
 int set_gemm_tile_config(int tile) {

@@ -229,18 +229,16 @@ int launch_w8(const GemmArgs& p, hipStream_t st) {
   int num_cu = 0;
   CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(kern), W_SMEM, &num_cu));
   const int tiles = (int)((p.M + 255) / 256) * (p.N / 256);
-  static const int env_grid = getenv("CACO_W8_MAXGRID") ? atoi(getenv("CACO_W8_MAXGRID")) : 0;     // experiments: fewer CUs
-  const int cus = env_grid > 0 && env_grid < num_cu ? env_grid : num_cu;
-  const int grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus / 8 * 8;
+  const int grid = tiles < num_cu ? (tiles + 7) / 8 * 8 : num_cu / 8 * 8;
   GemmArgs q = p;
   {   // n-tiles per L2 group (w4_decode).  An XCD's 32 workgroups run 32 consecutive tiles at a time; with n fastest over
       // all of N the weight rows they touch (N x K bf16: 4.7 MB for fc1) exceed the XCD's 4 MiB L2 and are re-streamed
       // through it once per M panel.  Groups of 4 n-tiles at K <= 1024 keep the group's weights (1.5 MB) plus the eight
       // A panels in flight (3.1 MB) resident: fabric reads of one fc1 launch 1.15 -> 0.81 GB by the TCC counters
       // (profiles/r2_v3), time -0.5 %.  Bytes are what the power cap prices, so it is on by default since
-      // round 3; CACO_W_NGROUP=<n> forces a group width, CACO_W_NGROUP=0 restores one group (read at every launch).
-    const char* env = getenv("CACO_W_NGROUP");
-    const int env_g = env ? atoi(env) : -1;
+      // round 3 (NOT re-timed at HEAD: no GPU since); switch SW_W_NGROUP / CACO_W_NGROUP=<n> forces a group width, 0 restores
+      // one group.  A caller's explicit p.ngroup (the ping-pong traversal asks for one group) overrides the switch.
+    const int env_g = sw(SW_W_NGROUP);
     const int tiles_n = p.N / 256;
     int g = tiles_n;
     if (tiles_n > 4 && p.K <= 1024) {           // equal groups where N allows: fc1 12 -> 3 x 4, QKV 9 -> 3 x 3
@@ -268,7 +266,7 @@ int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
   CACO_REQUIRE(gemm_bf16_w8_ok(p, epi), "gemm_bf16_w8: shape not supported");
   // compile-time specialised epilogues (w8_epilogue MODE): 1 bias only, 2 bias + residual, 3 bias + LayerNorm-fold consumer,
   // 4 bias + residual + fold producer (bf16 copy + row sums), 5 bias + gathered residual; 0 = generic (tested at run time)
-  static const bool generic = getenv("CACO_W8_GENERIC") && atoi(getenv("CACO_W8_GENERIC"));
+  constexpr bool generic = false;
   const bool plain_args = p.bias && !p.fold_mr && !p.xb_out && !p.stats_part;
   const bool plain = !generic && plain_args;
   if (plain && epi == EPI_BF16 && !p.resid) {

@@ -26,11 +26,15 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 //     < 0 wraps past the descriptor's range and reads as 0.  The patch-embed GEMM's positional embedding (api.hip).
 // Global I/O goes through raw buffer descriptors anchored at the wave's tile corner: 32-bit offsets, and rows past M
 // fall outside num_records, so stores need no exec mask and always count NST in vmcnt.  The ROW part of every offset is in
-// the per-lane (VGPR) offset: that is the only part the hardware range-checks - the scalar offset operand is "excluded
-// from bounds checking" (LLVM's definition of the raw.buffer intrinsics).  Rounds 1-2 stepped through the row blocks with
-// the scalar offset, which leaves the rows of a ragged last M tile unprotected (found in round 3 on the wavesim build once
-// its descriptor model followed that definition: heap corruption at M % 256 != 0); only the column half j * 128, which is
-// always inside a valid row's 256-byte span, still rides in the scalar offset.
+// the per-lane (VGPR) offset: under the LLVM-documented model of the raw.buffer intrinsics that is the only part the range
+// check covers (the scalar offset operand is "excluded from bounds checking"); the gfx9-family ISA manuals read the other
+// way for raw buffers (out of range when offset >= num_records - sgpr_offset), and no GPU has been available since round 2
+// to settle it on this chip.  The per-lane form is safe under BOTH models.  Rounds 1-2 stepped through the row blocks with
+// the scalar offset; under the LLVM model that leaves the rows of a ragged last M tile unprotected (the wavesim build, whose
+// descriptor follows that model, corrupts the heap at M % 256 != 0 with the old form) - whether the hardware of rounds 1-2
+// really wrote past row M is NOT established (tests/test_gpu_ops.py::test_gemm_ragged_m_writes_nothing_past_row_m is the
+// hardware check; tools/build_variant.sh can rebuild the old form for it).  Only the column half j * 128, which is always
+// inside a valid row's 256-byte span, still rides in the scalar offset.
 // (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
 // the epilogue - is 30-40 % SLOWER on the QKV / fc1 shapes: partial-line writes from 32 rows per instruction.)
 // Cache-policy bits of the epilogue's stores / residual loads: 2 = nt (streaming).  The outputs are far larger than the

@@ -46,6 +46,22 @@ int prepare_launch(const void* kern, int dyn_lds_bytes, int* num_cu);      // ap
     if (_rc) return _rc;     \
   } while (0)
 
+// Run-time switches (A/B experiments and diagnostics; api.hip).  Each takes its initial value from the environment variable of
+// the same name ONCE, at first use in the process; afterwards only caco_set_switch (include/caco_hip.h) changes it.  No launch
+// path calls getenv.
+enum Switch {
+  SW_PINGPONG,        // CACO_PINGPONG       0     consecutive kernels of an audio layer walk the rows in opposite directions
+  SW_POS_FUSE,        // CACO_POS_FUSE       0     positional embedding inside the patch-embed GEMM's epilogue
+  SW_POOL_FUSE,       // CACO_POOL_FUSE      0     final LayerNorm of encode_audio inside the pooling kernel
+  SW_ATTN_SMALL,      // CACO_ATTN_SMALL     0     one-wave attention kernel for sequences <= 64 (the text tower)
+  SW_ATTN_ROWS,       // CACO_ATTN_ROWS      64    32 = one query block per wave at every sequence length
+  SW_W_NGROUP,        // CACO_W_NGROUP       -1    n-tiles per L2 group of the persistent GEMM (-1 = by shape, 0 = one group)
+  SW_W8_MIN_TILES,    // CACO_W8_MIN_TILES   128   256 x 128 tile units from which the persistent GEMM is the default
+  SW_W4H_MAX_TILES,   // CACO_W4H_MAX_TILES  0     shapes below this many 256 x 256 tiles take 128 x 256 tiles (gemm_w4h.hip)
+  SW_COUNT
+};
+int sw(Switch s);
+
 int gemm_tile_config();
 int set_gemm_tile_config(int tile);
 int gemm_bf16(const GemmArgs& p, int epi, int act, hipStream_t st);

@@ -274,10 +274,14 @@ __global__ __launch_bounds__(256) void pos_prepare_kernel(const float* __restric
   const int64_t m = (int64_t)(blockIdx.x - table_blocks) * 256 + threadIdx.x;
   if (m >= rows) return;
   const float t = time_inds[m];
-  int f = (int)freq_inds[m];
-  f = f < 0 ? 0 : (f >= num_freq ? num_freq - 1 : f);
-  const int ti = (int)t;
-  idx[m] = (t >= 0.f && t < (float)tmax && (float)ti == t) ? ti * num_freq + f : -1;
+  const float ff = freq_inds[m];
+  const int f = !(ff >= 0.f) ? 0 : (ff >= (float)num_freq ? num_freq - 1 : (int)ff);   // clamp before the conversion (NaN -> 0)
+  int id = -1;
+  if (t >= 0.f && t < (float)tmax) {           // the conversion only for a value known to be in range (a NaN fails both tests)
+    const int ti = (int)t;
+    if ((float)ti == t) id = ti * num_freq + f;
+  }
+  idx[m] = id;
 }
 
 __global__ __launch_bounds__(256) void add_pos_embed_rest_kernel(float* __restrict__ x, const float* __restrict__ time_inds,
@@ -328,7 +332,7 @@ int layernorm(const float* x, const float* gamma, const float* beta, int64_t row
   CACO_REQUIRE(rows > 0 && x && gamma && beta && (out_f32 || out_bf16), "layernorm: bad arguments");
   // streaming (nt) reads of the fp32 rows when only the bf16 copy is produced (pre-LN stacks): x is not needed again
   // before the next GEMM rewrites it, and the bf16 rows this kernel writes are what should stay cached
-  static const int nt_env = getenv("CACO_LN_NT") ? atoi(getenv("CACO_LN_NT")) : 1;      // measured -1.1 % per step
+  constexpr int nt_env = 1;                   // measured -1.1 % per step (round 1)
   if (order == 1 || order == 2) {
     const int64_t nblk = (rows + 3) / 4;
     const int per_range = (int)((nblk + 7) / 8);

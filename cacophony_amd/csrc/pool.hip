@@ -277,14 +277,20 @@ int attn_pool_rows(const bf16_t* x, const float* wq, const float* mask, int batc
   CACO_REQUIRE(x && wq && out && batch > 0 && seq > 0, "attn_pool: bad arguments");
   CACO_REQUIRE(heads == 1 || heads % 2 == 0, "attn_pool: %d pooling heads unsupported (1 or an even number)", heads);
   CACO_REQUIRE(hidden % 4 == 0 && hidden <= 256 * PMAXC, "attn_pool: hidden %d must be a multiple of 4, <= %d", hidden, 256 * PMAXC);
-  // two heads per launch (the register budget of one pass over the rows); more heads - the JAX checkpoints pool with 8,
-  // src/caco/load_model.py:46 - take heads / 2 passes, each writing its head pair of the [batch, heads, hidden] output
-  const int per = heads == 1 ? 1 : 2;
+  // two heads per pass over the rows (the reference's pooler); more heads - the JAX checkpoints pool with 8,
+  // src/caco/load_model.py:46 - take four per pass when they divide (x is read heads / 4 times instead of heads / 2), each
+  // launch writing its heads of the [batch, heads, hidden] output
+  const int per = heads == 1 ? 1 : (heads % 4 == 0 ? 4 : 2);
   const size_t smem = (size_t)PW * per * (hidden + 2) * sizeof(float);
   CACO_REQUIRE(smem <= 160 * 1024, "attn_pool: hidden %d too large for the LDS combine buffer", hidden);
   if (heads == 1) {
     CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<1>), 160 * 1024, nullptr));
     hipLaunchKernelGGL(pool_rows_kernel<1>, dim3(batch), dim3(PW * 64), smem, st, x, wq, mask, seq, hidden, out, 1);
+  } else if (per == 4) {
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<4>), 160 * 1024, nullptr));
+    for (int h0 = 0; h0 < heads; h0 += 4)
+      hipLaunchKernelGGL(pool_rows_kernel<4>, dim3(batch), dim3(PW * 64), smem, st, x, wq + (size_t)h0 * hidden, mask, seq, hidden,
+                         out + (size_t)h0 * hidden, heads);
   } else {
     CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(pool_rows_kernel<2>), 160 * 1024, nullptr));
     for (int h0 = 0; h0 < heads; h0 += 2)

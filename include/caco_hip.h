@@ -194,11 +194,18 @@ void caco_decode_end(caco_decode_state* s);
 int64_t caco_workspace_bytes(const caco_model* m);
 /* Tuning knob (process-global): bf16 GEMM kernel choice.  256 (default) = per shape: the persistent 256x256 eight-wave
  * kernel (csrc/gemm_w8.hip) when every CU gets work, else the 256x128 two-workgroups-per-CU kernel (gemm_x.hip), else
- * 128x128; 128 = always 128x128 (env CACO_GEMM_TILE=128 selects it at first use).  Forced kernels for tests / A-B runs:
- * 8256 = gemm_w8, 2256 = gemm_x, 4256 = gemm_w4q (four waves of 128 x 128), 4128 = gemm_w4h (128 x 256 tiles for mid-size M): round-3 experiments, never the default.  A
- * forced kernel that does not support a shape falls back to the default choice.  Returns the mode now in force; any
- * other value only queries. */
+ * 128x128; 128 = always 128x128.  Forced kernels for tests / A-B runs: 8256 = gemm_w8, 2256 = gemm_x, 4256 = gemm_w4q
+ * (four waves of 128 x 128), 4128 = gemm_w4h (128 x 256 tiles for mid-size M): round-3 experiments, never the default.  A
+ * forced kernel that does not support a shape or an epilogue falls back to the default choice.  Returns the mode now in
+ * force; any other value only queries. */
 int32_t caco_set_gemm_tile(int32_t tile);
+/* Run-time switches of the A/B experiments (process-global diagnostics; csrc/kernels.h lists them with their defaults:
+ * CACO_PINGPONG, CACO_POS_FUSE, CACO_POOL_FUSE, CACO_ATTN_SMALL, CACO_ATTN_ROWS, CACO_W_NGROUP, CACO_W8_MIN_TILES,
+ * CACO_W4H_MAX_TILES).  A switch takes its initial value from the environment variable of the same name ONCE, at its first
+ * use in the process; afterwards only caco_set_switch changes it (no launch path reads the environment).  Unknown name:
+ * CACO_ERR_INVALID resp. INT32_MIN.  The reference has no counterpart: its knobs are Python arguments. */
+int caco_set_switch(const char* name, int32_t value);
+int32_t caco_get_switch(const char* name);
 /* Tuning knob: LayerNorm folding in the audio stack (the LayerNorm passes disappear into the neighbouring GEMM
  * epilogues; api.hip run_audio_layers).  0 = separate LayerNorm passes (default: measured slightly faster at batch
  * 256, see api.hip), 1 = always fold, -1 = fold when the batch fills the chip.  Env CACO_LN_FOLD sets the initial

@@ -34,8 +34,19 @@ def _is_experimental(item):
     return cs is not None and (cs.params.get("tile") in EXPERIMENTAL_TILES or cs.params.get("ln_fold") == 1)
 
 
+@pytest.hookimpl(tryfirst=True)
 def pytest_collection_modifyitems(config, items):
-    """Default-path cases first (file order kept), experimental ones last: the driver runs `pytest -x`."""
+    """Default-path cases first (file order kept), experimental ones last: the driver runs `pytest -x`.  The experimental
+    cases carry the marker (so `-m "gpu and not experimental"` works for parametrised tile codes too) and are SKIPPED unless
+    CACO_RUN_EXPERIMENTAL=1 (tools/gpu_session.sh sets it for its second pytest pass) or the suite runs on the simulator:
+    a plain `pytest -m gpu` is the product's parity record and nothing else."""
+    run_exp = os.environ.get("CACO_RUN_EXPERIMENTAL") == "1" or os.environ.get("CACO_GPU_ON_SIM") == "1"
+    for it in items:
+        if _is_experimental(it):
+            if it.get_closest_marker("experimental") is None:
+                it.add_marker(pytest.mark.experimental)
+            if not run_exp and it.get_closest_marker("gpu") is not None:
+                it.add_marker(pytest.mark.skip(reason="experimental kernel / opt-in switch: set CACO_RUN_EXPERIMENTAL=1"))
     items.sort(key=lambda it: 1 if _is_experimental(it) else 0)      # list.sort is stable
 
 
@@ -91,6 +102,24 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture
+def caco_switch():
+    """caco_switch(lib, "CACO_POS_FUSE", 1): set a run-time switch of `lib` (the product library or the simulator build) through
+    caco_set_switch; every switch touched is restored when the test ends.  value None = the switch's built-in default."""
+    undo = []
+
+    def set_(lib, name, value):
+        defaults = {"CACO_ATTN_ROWS": 64, "CACO_W_NGROUP": -1, "CACO_W8_MIN_TILES": 128}
+        prev = lib.caco_get_switch(name.encode())
+        assert prev != -2 ** 31, f"unknown switch {name}"
+        assert lib.caco_set_switch(name.encode(), int(defaults.get(name, 0) if value is None else value)) == 0
+        undo.append((lib, name, prev))
+
+    yield set_
+    for lib, name, prev in reversed(undo):
+        lib.caco_set_switch(name.encode(), prev)
 
 
 @pytest.fixture(scope="session")

@@ -48,6 +48,21 @@ def load() -> C.CDLL:
     return lib
 
 
+SWITCHES = ("CACO_PINGPONG", "CACO_POS_FUSE", "CACO_POOL_FUSE", "CACO_ATTN_SMALL", "CACO_ATTN_ROWS", "CACO_W_NGROUP",
+            "CACO_W8_MIN_TILES", "CACO_W4H_MAX_TILES")
+_SWITCH_DEFAULTS = {"CACO_ATTN_ROWS": 64, "CACO_W_NGROUP": -1, "CACO_W8_MIN_TILES": 128}
+
+
+def sync_switches(lib=None) -> None:
+    """Push the CACO_* switch variables of os.environ into the library (caco_set_switch): the library reads its environment
+    once per switch, so a driver script that flips os.environ between cases calls this after every change.  A variable that
+    is absent means the switch's built-in default."""
+    lib = lib or load()
+    for name in SWITCHES:
+        v = os.environ.get(name)
+        lib.caco_set_switch(name.encode(), int(v) if v not in (None, "") else _SWITCH_DEFAULTS.get(name, 0))
+
+
 def check(status: int, what: str = "") -> None:
     if status == 0:
         return

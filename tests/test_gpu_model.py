@@ -499,7 +499,7 @@ def test_unindexed_device_and_host_inputs_to_encode_pairs(tiny_state):
 
 
 @pytest.mark.experimental
-def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
+def test_pos_embed_in_the_patch_embed_epilogue(full_model, caco_switch):
     """CACO_POS_FUSE=1: the positional embedding as a gathered residual of the patch-embed GEMM instead of a separate pass
     (same case as tests/test_wavesim.py, at a batch the persistent kernel is the default for).  Same hidden states up to fp32
     re-association and the bf16 operand flips it causes downstream; rows whose time index is not a small integer take the exact per-row kernel and are bit-identical."""
@@ -510,7 +510,7 @@ def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
     tin[0, 9] = -1.0
     outs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("CACO_POS_FUSE", flag)
+        caco_switch(_lib.load(), "CACO_POS_FUSE", flag)
         emb, hid = full_model.get_audio_embedding(ab["audio_patches"], tin, ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
         outs[flag] = (emb.cpu().numpy(), hid.cpu().numpy())
     assert np.isfinite(outs["1"][1]).all()
@@ -522,11 +522,11 @@ def test_pos_embed_in_the_patch_embed_epilogue(full_model, monkeypatch):
 
 
 @pytest.mark.experimental
-def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch):
+def test_round3_switches_against_the_goldens(full_model, tiny_state, caco_switch):
     """Every round-3 opt-in at once (fused positional embedding, short-sequence attention kernel) against the reference's
     own outputs, full and tiny configuration."""
-    monkeypatch.setenv("CACO_POS_FUSE", "1")
-    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    caco_switch(_lib.load(), "CACO_POS_FUSE", "1")
+    caco_switch(_lib.load(), "CACO_ATTN_SMALL", "1")
     _check_against_golden(full_model, load_golden("caco_full.npz"), 4, 50265)
     a, t, cc = C.tiny_configs(2)
     tm = CACO(a, t, cc, device=DEV).load_state_dict(tiny_state)
@@ -538,14 +538,14 @@ def test_round3_switches_against_the_goldens(full_model, tiny_state, monkeypatch
 
 
 @pytest.mark.experimental
-def test_final_layernorm_inside_the_pooler(full_model, monkeypatch):
+def test_final_layernorm_inside_the_pooler(full_model, caco_switch):
     """CACO_POOL_FUSE=1 (same case as tests/test_wavesim.py): encode_audio's final LayerNorm applied inside the pooling kernel."""
     wav = synth.make_waveforms(6, start=11)
     w = torch.from_numpy(wav).to(DEV)
     lens = [160000, 160000, 90000, 40000, 160000, 12345]
     embs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("CACO_POOL_FUSE", flag)
+        caco_switch(_lib.load(), "CACO_POOL_FUSE", flag)
         embs[flag] = full_model.encode_audio(w, lengths=lens).cpu().numpy()
     assert np.isfinite(embs["1"]).all()
     assert cosine_rows(embs["1"], embs["0"]).min() > 0.99999
@@ -568,12 +568,12 @@ def test_audio_pooler_head_counts_match_reference(tiny_state, heads):
 
 
 @pytest.mark.experimental
-def test_pingpong_traversal_changes_nothing_but_the_order(full_model, monkeypatch):
+def test_pingpong_traversal_changes_nothing_but_the_order(full_model, caco_switch):
     """CACO_PINGPONG=1 (same case as tests/test_wavesim.py, at a batch the persistent kernels are the default for): pure
     re-ordering of independent work, so the embeddings are bitwise those of the default order."""
     wav = torch.from_numpy(synth.make_waveforms(44, start=3)).to(DEV)          # not a multiple of 8: the last clips keep the plain order
     outs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("CACO_PINGPONG", flag)
+        caco_switch(_lib.load(), "CACO_PINGPONG", flag)
         outs[flag] = full_model.encode_audio(wav).cpu().numpy()
     np.testing.assert_array_equal(outs["1"], outs["0"])

@@ -355,7 +355,7 @@ def test_mel_lengths_bound_the_sample_fetch():
 @pytest.mark.parametrize("B,Sq,S,heads,causal,valid", [
     (256, 32, 32, 12, 1, None), (5, 32, 32, 3, 0, [32, 7, 20, 32, 1]), (2, 64, 64, 12, 1, [64, 33]), (2, 37, 37, 2, 1, [37, 5]),
     (2, 20, 50, 12, 0, [50, 33]), (3, 1, 64, 12, 0, [64, 2, 1]), (1, 33, 33, 1, 0, [0])])
-def test_attention_small_kernel(lib, monkeypatch, B, Sq, S, heads, causal, valid):
+def test_attention_small_kernel(lib, caco_switch, B, Sq, S, heads, causal, valid):
     """attention_small.hip (one wave per (clip, head, 32-query block); opt-in through CACO_ATTN_SMALL) against the torch
     checker and against the big kernel.  Same cases as tests/test_wavesim.py, plus the text tower's batch."""
     hd = 64
@@ -369,7 +369,7 @@ def test_attention_small_kernel(lib, monkeypatch, B, Sq, S, heads, causal, valid
         mask[i, :n] = 1
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("CACO_ATTN_SMALL", flag)
+        caco_switch(lib, "CACO_ATTN_SMALL", flag)
         out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16, device=DEV)
         _lib.check(lib.caco_op_attention_qkv(_p(q), H, Sq, _p(kv), 2 * H, 0, H, _p(mask), B, S, heads, hd, causal, _p(out), _st()))
         torch.cuda.synchronize()

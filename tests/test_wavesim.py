@@ -383,14 +383,14 @@ def test_mel_lengths_bound_the_sample_fetch(sim):
 
 
 @pytest.mark.parametrize("ngroup", ["0", "2", "4", None])
-def test_gemm_w8_n_tile_groups(sim, ngroup, monkeypatch):
+def test_gemm_w8_n_tile_groups(sim, ngroup, caco_switch):
     """The persistent kernel's tile order in groups of n-tiles (w4_decode; default since round 3: groups of 3-4 at
     K <= 1024): equal groups, a ragged last group (5 n-tiles in groups of 2 / 4), one group; both cursors (operand
     prefetch and epilogue) must decode the same order."""
     if ngroup is None:
-        monkeypatch.delenv("CACO_W_NGROUP", raising=False)
+        caco_switch(sim, "CACO_W_NGROUP", None)
     else:
-        monkeypatch.setenv("CACO_W_NGROUP", ngroup)
+        caco_switch(sim, "CACO_W_NGROUP", ngroup)
     sim.caco_set_gemm_tile(8256)
     for (M, N, K) in ((700, 1280, 128), (520, 2304, 64)):      # 3 x 5 and 3 x 9 tiles
         a = _rand((M, K), 1).bfloat16()
@@ -411,7 +411,7 @@ def test_gemm_w8_n_tile_groups(sim, ngroup, monkeypatch):
     (2, 20, 50, 2, 0, [50, 33]),           # cross-attention lengths
     (2, 1, 64, 2, 0, [64, 2]),             # a single query row (a cached decode step)
     (1, 33, 33, 1, 0, [0])])               # every key masked: rows of zeros, no NaN
-def test_attention_small_kernel(sim, monkeypatch, B, Sq, S, heads, causal, valid):
+def test_attention_small_kernel(sim, caco_switch, B, Sq, S, heads, causal, valid):
     """attention_small.hip (one wave per (clip, head, 32-query block), opt-in) against the same checker as the big kernel,
     and against the big kernel itself."""
     hd = 64
@@ -423,7 +423,7 @@ def test_attention_small_kernel(sim, monkeypatch, B, Sq, S, heads, causal, valid
         mask[i, :n] = 1
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("CACO_ATTN_SMALL", flag)
+        caco_switch(sim, "CACO_ATTN_SMALL", flag)
         out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16)
         simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, P(mask), B, S, heads, hd, causal, P(out), None))
         outs[flag] = out.float()
@@ -437,14 +437,14 @@ def test_attention_small_kernel(sim, monkeypatch, B, Sq, S, heads, causal, valid
     assert (outs["1"][~live] == 0).all()
     assert (outs["1"] - outs["0"]).abs().max().item() < 0.02
     # no mask pointer
-    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    caco_switch(sim, "CACO_ATTN_SMALL", "1")
     out = torch.full((B, Sq, H), float("nan"), dtype=torch.bfloat16)
     simlib.check(sim.caco_op_attention_qkv(P(q), H, Sq, P(kv), 2 * H, 0, H, None, B, S, heads, hd, causal, P(out), None))
     ref = _attention_ref(q, kv[..., :H], kv[..., H:], None, heads, hd, bool(causal))
     assert (out.float() - ref).abs().max().item() < 0.03
 
 
-def test_pos_embed_in_the_patch_embed_epilogue(sim, tiny_state, monkeypatch):
+def test_pos_embed_in_the_patch_embed_epilogue(sim, tiny_state, caco_switch):
     """CACO_POS_FUSE=1: the positional embedding as a gathered residual of the patch-embed GEMM (w8 MODE 5) instead of a
     separate pass.  Same hidden states as the separate kernel (fp32 re-association only), also for positions that are not
     small integers (those rows are finished by the exact per-row kernel) and for a ragged last M tile."""
@@ -462,7 +462,7 @@ def test_pos_embed_in_the_patch_embed_epilogue(sim, tiny_state, monkeypatch):
     try:
         outs = {}
         for flag in ("0", "1"):
-            monkeypatch.setenv("CACO_POS_FUSE", flag)
+            caco_switch(sim, "CACO_POS_FUSE", flag)
             _, hid = m.audio_forward(ab["audio_patches"], tin, ab["audio_freq_inds"], ab["audio_mask"])
             outs[flag] = hid.numpy()
     finally:
@@ -477,11 +477,11 @@ def test_pos_embed_in_the_patch_embed_epilogue(sim, tiny_state, monkeypatch):
     assert rel_l2(outs["1"], ref) < 5e-3
 
 
-def test_tiny_config_golden_with_round3_switches(sim, tiny_state, monkeypatch):
+def test_tiny_config_golden_with_round3_switches(sim, tiny_state, caco_switch):
     """The 2-layer towers against the reference golden with every round-3 opt-in on at once (fused positional embedding,
     short-sequence attention kernel), on the persistent GEMM."""
-    monkeypatch.setenv("CACO_POS_FUSE", "1")
-    monkeypatch.setenv("CACO_ATTN_SMALL", "1")
+    caco_switch(sim, "CACO_POS_FUSE", "1")
+    caco_switch(sim, "CACO_ATTN_SMALL", "1")
     sim.caco_set_gemm_tile(8256)
     try:
         test_tiny_config_matches_reference_golden(sim, tiny_state, 0)
@@ -710,7 +710,7 @@ def test_random_shape_sweep(sim):
 
 
 @pytest.mark.parametrize("pool_heads", [2, 8])
-def test_final_layernorm_inside_the_pooler(sim, tiny_state, monkeypatch, pool_heads):
+def test_final_layernorm_inside_the_pooler(sim, tiny_state, caco_switch, pool_heads):
     """CACO_POOL_FUSE=1: encode_audio's final LayerNorm applied inside the pooling kernel (no normalised rows written).
     Same embeddings as the two-launch form up to the bf16 rounding of the rows it no longer takes, and within the parity
     bars of the oracle; ragged clip lengths (masked tokens, a clip shorter than the window)."""
@@ -726,7 +726,7 @@ def test_final_layernorm_inside_the_pooler(sim, tiny_state, monkeypatch, pool_he
         wav[i, L:] = 0
     embs = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("CACO_POOL_FUSE", flag)
+        caco_switch(sim, "CACO_POOL_FUSE", flag)
         embs[flag] = m.encode_audio(wav, lengths=lens).numpy()
     ref = np.concatenate([o.encode_audio(wav[i:i + 1, :L], max(8, n * 8 // 160 // 16)) for i, L in enumerate(lens)], 0)
     assert np.isfinite(embs["1"]).all()
@@ -753,14 +753,14 @@ def test_audio_pooler_head_counts_match_reference(sim, tiny_state, heads):
 
 @pytest.mark.skipif(os.environ.get("CACO_SIM_FULL", "0") in ("", "0"), reason="set CACO_SIM_FULL=1: the 12 + 12-layer model on the simulator (~5 min)")
 @pytest.mark.parametrize("variant", ["default", "w8_and_round3_switches"])
-def test_full_config_matches_reference_golden(sim, full_state, monkeypatch, variant):
+def test_full_config_matches_reference_golden(sim, full_state, caco_switch, variant):
     """tests/test_gpu_model.py::test_full_config_matches_reference_golden on the simulator: the full 12 + 12-layer model,
     4 clips + 4 captions, against the reference's own outputs (tests/golden/caco_full.npz), incl. the centred cosine -
     with the kernels a batch of 4 gets by default, and with the persistent GEMM forced plus every round-3 switch on.
     Recorded in profiles/r3_cpu/wavesim_runs.txt."""
     if variant != "default":
         for k in ("CACO_ATTN_SMALL", "CACO_POS_FUSE", "CACO_POOL_FUSE"):
-            monkeypatch.setenv(k, "1")
+            caco_switch(sim, k, 1)
         sim.caco_set_gemm_tile(8256)
     try:
         _full_config_golden(sim, full_state)
@@ -796,7 +796,7 @@ def _full_config_golden(sim, full_state):
 
 
 @pytest.mark.parametrize("B,n", [(9, 20480), (16, 5120), (3, 41000)])
-def test_pingpong_traversal_changes_nothing_but_the_order(sim, tiny_state, monkeypatch, B, n):
+def test_pingpong_traversal_changes_nothing_but_the_order(sim, tiny_state, caco_switch, B, n):
     """CACO_PINGPONG=1: consecutive kernels of a layer walk the rows in opposite directions inside the 8 ranges the XCDs own
     (reversed tile lists, range-ordered LayerNorm, contiguous clips per XCD in attention).  Pure re-ordering of independent
     work: hidden states and embeddings are BITWISE those of the default order - for batches that are and are not multiples
@@ -809,7 +809,7 @@ def test_pingpong_traversal_changes_nothing_but_the_order(sim, tiny_state, monke
     try:
         outs = {}
         for flag in ("0", "1"):
-            monkeypatch.setenv("CACO_PINGPONG", flag)
+            caco_switch(sim, "CACO_PINGPONG", flag)
             emb, hid = m.audio_forward(ab["audio_patches"], ab["audio_time_inds"], ab["audio_freq_inds"], ab["audio_mask"], normalize=True)
             outs[flag] = (emb.numpy().copy(), hid.numpy().copy())
     finally:

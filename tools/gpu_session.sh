@@ -14,8 +14,10 @@ export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 if want truth; then
 echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
-(timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -40) > "$OUT/pytest_gpu.txt"
+(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > "$OUT/pytest_gpu.txt"                  # the product: default path only
 tail -3 "$OUT/pytest_gpu.txt"
+(CACO_RUN_EXPERIMENTAL=1 timeout 900 python -m pytest tests -m "gpu and experimental" -q 2>&1 | tail -40) > "$OUT/pytest_gpu_experimental.txt"   # never-default kernels, opt-in switches (no -x)
+tail -3 "$OUT/pytest_gpu_experimental.txt"
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > "$OUT/smoke.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"

@@ -18,9 +18,9 @@ one cal_fetch FETCH_SIZE tools/probes/mall_probe
 one cal_write WRITE_SIZE tools/probes/mall_probe
 one gemm_fetch FETCH_SIZE python tools/gemm_bench.py --iters 3 --only $ONLY --tile $TILE
 one gemm_write WRITE_SIZE python tools/gemm_bench.py --iters 3 --only $ONLY --tile $TILE
-python - "$OUT" "$ONLY" <<'PY'
+python - "$OUT" "$ONLY" "${CACO_W_NGROUP:--1}" <<'PY'
 import csv, json, sys
-out, only = sys.argv[1], sys.argv[2]
+out, only, w_ngroup = sys.argv[1], sys.argv[2], int(sys.argv[3])
 def rows(name):
     return list(csv.DictReader(open(f"{out}/{name}.csv")))
 def val(name, key, ctr):
@@ -35,7 +35,8 @@ kf, kw = mean_bytes / f_rd, mean_bytes / w_wr          # bytes per counter unit
 gf, n = val("gemm_fetch", "gemm_bf16", "FETCH_SIZE")
 gw, _ = val("gemm_write", "gemm_bf16", "WRITE_SIZE")
 res = {"shape": only, "fetch_counter": gf, "write_counter": gw, "bytes_per_fetch_unit": kf, "bytes_per_write_unit": kw,
-       "hbm_read_bytes": gf * kf, "hbm_write_bytes": gw * kw, "hbm_bytes": gf * kf + gw * kw, "dispatches": n}
+       "hbm_read_bytes": gf * kf, "hbm_write_bytes": gw * kw, "hbm_bytes": gf * kf + gw * kw, "dispatches": n,
+       "w_ngroup": w_ngroup}     # the tile order measured (switch CACO_W_NGROUP: -1 = groups by shape, 0 = one group): bench.py only quotes a matching file
 json.dump(res, open(f"{out}/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(res))
 PY

@@ -26,6 +26,9 @@ for name, (res, args) in _lib._SIGNATURES.items():
 P = lambda a: C.c_void_p(0 if a is None else a.ctypes.data)
 def chk(rc, what=""):
     assert rc == 0, (what, lib.caco_last_error())
+def sync_switches():       # the library reads its environment once per switch: push os.environ's CACO_* values through the ABI
+    for name in ("CACO_ATTN_SMALL", "CACO_POS_FUSE", "CACO_POOL_FUSE", "CACO_PINGPONG"):
+        lib.caco_set_switch(name.encode(), int(os.environ.get(name, "0") or 0))
 def bf16(x):
     u = np.ascontiguousarray(x, np.float32).view(np.uint32)
     return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
@@ -42,6 +45,7 @@ for tile in (128, 2256, 8256, 4256, 4128):
 lib.caco_set_gemm_tile(256)
 for env in ("0", "1"):
     os.environ["CACO_ATTN_SMALL"] = env
+    sync_switches()
     for (B, S, heads, hd, causal) in ((2, 197, 2, 96, 0), (3, 31, 3, 64, 1), (1, 130, 1, 96, 1), (2, 61, 2, 64, 0)):
         H = heads * hd
         qkv = bf16(rng.standard_normal((B, S, 3 * H)))
@@ -71,6 +75,7 @@ chk(lib.caco_finalize_weights(h), "finalize")
 for flags in (("0", "0"), ("1", "1")):
     os.environ["CACO_POS_FUSE"], os.environ["CACO_ATTN_SMALL"] = flags
     os.environ["CACO_POOL_FUSE"] = os.environ["CACO_PINGPONG"] = flags[0]
+    sync_switches()
     lib.caco_set_gemm_tile(8256 if flags[0] == "1" else 256)
     wav = (rng.standard_normal((3, 33000)) * 0.1).astype(np.float32)
     emb = np.zeros((3, 768), np.float32)

@@ -42,6 +42,7 @@ del a, o
 
 for (B, S, heads, hd, causal, small) in ((7400, 64, 8, 96, 0, "0"), (15000, 32, 12, 64, 1, "0"), (15000, 32, 12, 64, 1, "1")):
     os.environ["CACO_ATTN_SMALL"] = small
+    simlib.sync_switches()
     H = heads * hd
     qkv = torch.randn(B * S, 3 * H, generator=g).bfloat16().view(B, S, 3 * H)
     mask = torch.ones(B, S)
@@ -61,6 +62,7 @@ for (B, S, heads, hd, causal, small) in ((7400, 64, 8, 96, 0, "0"), (15000, 32, 
         report(f"clip {c}", (out[c, :nv].float() - ref[:nv]).abs().max().item(), 0.03)
     del qkv, out
 os.environ.pop("CACO_ATTN_SMALL", None)
+simlib.sync_switches()
 
 rows, dim = 800000, 768
 x = torch.randn(rows, dim, generator=g)

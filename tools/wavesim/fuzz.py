@@ -81,6 +81,7 @@ def fuzz_attention(sim, rng, log):
     causal = int(rng.random() < 0.4)
     Sq = S if (causal or rng.random() < 0.6) else int(rng.choice([1, 5, 32, 33, 64, 130]))
     os.environ["CACO_ATTN_SMALL"] = "1" if rng.random() < 0.5 else "0"
+    simlib.sync_switches()
     H = heads * hd
     ld = 3 * H + (int(rng.choice([0, 8, 64])))              # padded row pitch
     qkv = torch.zeros(B, S, ld, dtype=torch.bfloat16)
@@ -104,6 +105,7 @@ def fuzz_attention(sim, rng, log):
     assert (out[B * Sq:] == GUARD).all(), ("attention wrote past its rows", B, Sq, S, heads, hd)
     log.append(f"attention B {B} Sq {Sq} S {S} heads {heads} hd {hd} causal {causal} small {os.environ['CACO_ATTN_SMALL']}")
     os.environ["CACO_ATTN_SMALL"] = "0"
+    simlib.sync_switches()
 
 
 def fuzz_layernorm(sim, rng, log):
@@ -193,6 +195,7 @@ def fuzz_model(sim, rng, log):
     os.environ["CACO_POS_FUSE"] = "1" if rng.random() < 0.5 else "0"
     os.environ["CACO_POOL_FUSE"] = "1" if rng.random() < 0.5 else "0"
     os.environ["CACO_PINGPONG"] = "1" if rng.random() < 0.5 else "0"
+    simlib.sync_switches()
     tile = int(rng.choice([256, 8256, 128]))
     sim.caco_set_gemm_tile(tile)
     m.set_ln_fold(int(rng.random() < 0.3))
@@ -221,6 +224,7 @@ def fuzz_model(sim, rng, log):
     sim.caco_set_gemm_tile(256)
     m.set_ln_fold(0)
     os.environ["CACO_ATTN_SMALL"] = os.environ["CACO_POS_FUSE"] = os.environ["CACO_POOL_FUSE"] = os.environ["CACO_PINGPONG"] = "0"
+    simlib.sync_switches()
     log.append(desc + f" cos {ca:.5f} {ct:.5f}")
 
 

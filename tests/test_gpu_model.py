@@ -18,7 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from cacophony_amd import config as C  # noqa: E402
-from cacophony_amd import frontend, synth  # noqa: E402
+from cacophony_amd import _lib, frontend, synth  # noqa: E402
 from cacophony_amd.model import CACO, AudioMAE, create_caco_model, similarity  # noqa: E402
 from oracle import caco_oracle as O  # noqa: E402
 from tests.conftest import cosine_rows, load_golden, rel_l2  # noqa: E402
@@ -577,3 +577,46 @@ def test_pingpong_traversal_changes_nothing_but_the_order(full_model, caco_switc
         caco_switch(_lib.load(), "CACO_PINGPONG", flag)
         outs[flag] = full_model.encode_audio(wav).cpu().numpy()
     np.testing.assert_array_equal(outs["1"], outs["0"])
+
+
+def test_tower_outputs_keep_their_guard_rows(tiny_model):
+    """caco_audio_forward / caco_text_forward write exactly emb [B, P] and hidden [B, S, H] (the poolers, the final LayerNorm,
+    the projection GEMMs and the normalisation all end in caller memory): sentinel rows before and after both outputs survive,
+    for a batch and sequence lengths that are multiples of no tile size."""
+    import ctypes as CT
+    lib, m = _lib.load(), tiny_model
+    G = 16
+
+    def guarded(rows, cols):
+        full = torch.full((rows + 2 * G, cols), 7.0, dtype=torch.float32, device=DEV)
+        return full, full[G:G + rows]
+
+    def intact(full, rows):
+        return bool((full[:G] == 7.0).all() and (full[G + rows:] == 7.0).all())
+
+    P = lambda t: CT.c_void_p(0 if t is None else t.data_ptr())
+    st = CT.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B, S = 3, 77
+    gen = torch.Generator().manual_seed(5)
+    patches = torch.randn(B, S, 256, generator=gen).to(DEV)
+    ar = torch.arange(S, dtype=torch.float32)
+    tin, fin = (ar // 8).repeat(B, 1).to(DEV), (ar % 8).repeat(B, 1).to(DEV)
+    mask = torch.ones(B, S, device=DEV)
+    mask[1, 40:] = 0
+    Hh, Pp = m.audio_config.hidden_size, m.caco_config.projection_size
+    for normalize in (0, 1):
+        emb_f, emb = guarded(B, Pp)
+        hid_f, hid = guarded(B * S, Hh)
+        _lib.check(lib.caco_audio_forward(m._handle, P(patches), 0, P(tin), P(fin), P(mask), B, S, normalize, P(emb), P(hid), st))
+        torch.cuda.synchronize()
+        assert intact(emb_f, B) and intact(hid_f, B * S)
+        assert torch.isfinite(emb).all() and torch.isfinite(hid).all()
+    T = 19
+    ids, tmask = synth.make_captions(B, T, m.text_config.vocab_size)
+    ids, tmask = torch.as_tensor(ids).to(DEV), torch.as_tensor(tmask).to(DEV)
+    emb_f, emb = guarded(B, Pp)
+    hid_f, hid = guarded(B * T, m.text_config.hidden_size)
+    _lib.check(lib.caco_text_forward(m._handle, P(ids), P(tmask), None, B, T, 1, P(emb), P(hid), st))
+    torch.cuda.synchronize()
+    assert intact(emb_f, B) and intact(hid_f, B * T)
+    assert torch.isfinite(emb).all() and torch.isfinite(hid).all()

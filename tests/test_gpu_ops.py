@@ -412,3 +412,49 @@ def test_gemm_ragged_m_writes_nothing_past_row_m(lib, tile, M):
     assert (out[M:] == 7.0).all() and (x[M:] == 7.0).all()
     assert torch.isfinite(out[:M].float()).all() and torch.isfinite(x[:M]).all()
     lib.caco_set_gemm_tile(256)
+
+
+GUARD_ROWS = 64
+
+
+def _guarded(rows, cols, dtype, value=7.0):
+    """A [rows, cols] output window in the middle of one allocation with GUARD_ROWS sentinel rows on either side."""
+    full = torch.full((rows + 2 * GUARD_ROWS, cols), value, dtype=dtype, device=DEV)
+    return full, full[GUARD_ROWS:GUARD_ROWS + rows]
+
+
+def _guards_intact(full, rows, value=7.0):
+    return bool((full[:GUARD_ROWS] == value).all() and (full[GUARD_ROWS + rows:] == value).all())
+
+
+@pytest.mark.parametrize("B,S,heads,hd,causal", [(2, 496, 8, 96, 0), (2, 500, 8, 96, 0), (1, 1500, 8, 96, 0), (3, 33, 12, 64, 1),
+                                                 (2, 130, 12, 64, 0), (1, 1, 8, 96, 0), (2, 257, 8, 96, 0)])
+def test_attention_writes_nothing_outside_its_rows(lib, B, S, heads, hd, causal):
+    """Sequence lengths that are not multiples of the 32 / 64-row query blocks or of the 64-key tiles (the bench shape's 496,
+    the reference's padded 500, the 30 s shape's 1500): the rows before and after the [B * S, H] output stay untouched, and the
+    LAST clip's last rows are the right ones (a clamped or wrapped row index would put another row's values there)."""
+    H = heads * hd
+    qkv = _rand((B, S, 3 * H), 60, 1.2).bfloat16().contiguous()
+    mask = torch.ones(B, S, device=DEV)
+    mask[-1, (S + 1) // 2:] = 0
+    full, out = _guarded(B * S, H, torch.bfloat16)
+    _lib.check(lib.caco_op_attention(_p(qkv), 3 * H, H, 2 * H, _p(mask), B, S, heads, hd, causal, _p(out), _st()))
+    torch.cuda.synchronize()
+    assert _guards_intact(full, B * S)
+    ref = _attention_ref(qkv[..., :2 * H], qkv[..., 2 * H:], mask, heads, hd, bool(causal))
+    assert (out.view(B, S, H).float() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("rows", [1, 3, 5, 1003])
+def test_layernorm_writes_nothing_outside_its_rows(lib, rows):
+    """Row counts that are not multiples of the rows a workgroup serves (4): both outputs keep their guard rows."""
+    dim = 768
+    x = _rand((rows, dim), 70, 2.0) + 0.3
+    g, b = _rand((dim,), 71), _rand((dim,), 72)
+    full_f, of = _guarded(rows, dim, torch.float32)
+    full_b, ob = _guarded(rows, dim, torch.bfloat16)
+    _lib.check(lib.caco_op_layernorm(_p(x), _p(g), _p(b), rows, dim, 1e-5, _p(of), _p(ob), _st()))
+    torch.cuda.synchronize()
+    assert _guards_intact(full_f, rows) and _guards_intact(full_b, rows)
+    ref = torch.nn.functional.layer_norm(x, (dim,), g, b, 1e-5)
+    assert (of - ref).abs().max().item() < 2e-5 and (ob.float() - ref).abs().max().item() < 0.04

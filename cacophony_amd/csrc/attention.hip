@@ -68,7 +68,9 @@ __device__ __forceinline__ bf16x8 v_frag_tr(const char* p) {
 }
 
 // (the body lives in a __device__ function: the buffer-descriptor builtins it uses are not visible to the host pass)
-template <int HD, bool CAUSAL, int NW, int QR>
+// ORD: the workgroup order is a run-time argument (ping-pong traversal, api.hip).  It is a template parameter so that the
+// default kernels (ORD = false) keep the instruction streams that ran on hardware in round 2 (tools/isa_diff.sh).
+template <int HD, bool CAUSAL, int NW, int QR, bool ORD>
 __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, int q_ld, int Sq, const bf16_t* __restrict__ kv, int ld,
                                                int k_off, int v_off, const float* __restrict__ key_mask, int S, int heads,
                                                bf16_t* __restrict__ out, float scale_log2, int kv_rows, int order) {
@@ -101,9 +103,14 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       const int w = slot % per_clip;
       // order 0: clip b on XCD b % 8.  order 1 / 2 (ping-pong traversal, api.hip): XCD x serves the contiguous clips
       // [x * b8/8, (x + 1) * b8/8) - the row range the persistent GEMMs' XCD x owns - first to last / last to first
-      const int k = slot / per_clip, nb = b8 >> 3;
-      const int kk = order == 2 ? nb - 1 - k : k;
-      b = order == 0 ? k * 8 + xcd : xcd * nb + kk;
+      const int k = slot / per_clip;
+      if constexpr (ORD) {
+        const int nb = b8 >> 3;
+        const int kk = order == 2 ? nb - 1 - k : k;
+        b = order == 0 ? k * 8 + xcd : xcd * nb + kk;
+      } else {
+        b = k * 8 + xcd;
+      }
       qb = w % gridDim.x;
       h = w / gridDim.x;
     }
@@ -346,12 +353,12 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
 }
 
 // workgroups per CU the register budget is held to: 3 (164 VGPRs) with one query block per wave, 2 (256) with two
-template <int HD, bool CAUSAL, int NW, int QR>
+template <int HD, bool CAUSAL, int NW, int QR, bool ORD = false>
 __global__ __launch_bounds__(NW * 64, QR == 1 ? 3 : 2) void attention_kernel(const bf16_t* __restrict__ q, int q_ld, int Sq,
                                                                const bf16_t* __restrict__ kv, int ld, int k_off, int v_off,
                                                                const float* __restrict__ key_mask, int S, int heads,
                                                                bf16_t* __restrict__ out, float scale_log2, int kv_rows, int order) {
-  attention_body<HD, CAUSAL, NW, QR>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows, order);
+  attention_body<HD, CAUSAL, NW, QR, ORD>(q, q_ld, Sq, kv, ld, k_off, v_off, key_mask, S, heads, out, scale_log2, kv_rows, order);
 }
 
 // experiment switch: CACO_ATTN_ROWS=32 keeps one query block per wave at every sequence length
@@ -387,8 +394,10 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   // keep 128-row workgroups
   const int qr = (!causal && seq_q > 128 && attention_rows_per_wave() != 32) ? 2 : 1;
   const dim3 grid((seq_q + NW * 32 * qr - 1) / (NW * 32 * qr), heads, batch);
-#define CACO_ATTN(HD_, C_, QR_) \
-  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows, order)
+#define CACO_ATTN_(HD_, C_, QR_, O_) \
+  hipLaunchKernelGGL((attention_kernel<HD_, C_, NW, QR_, O_>), grid, dim3(NW * 64), 0, st, q, q_ld, seq_q, qkv, ld, k_off, v_off, key_mask, seq, heads, out, scale_log2, kv_batch_rows, order)
+  // a non-default workgroup order (ping-pong traversal) exists for the audio tower's shape class only
+#define CACO_ATTN(HD_, C_, QR_) do { if (order != 0 && HD_ == 96 && !C_) CACO_ATTN_(96, false, QR_, true); else CACO_ATTN_(HD_, C_, QR_, false); } while (0)
 #define CACO_ATTN_QR(HD_, C_) do { if (qr == 2) CACO_ATTN(HD_, C_, 2); else CACO_ATTN(HD_, C_, 1); } while (0)
   if (head_dim == 96) {
     if (causal) CACO_ATTN(96, true, 1); else CACO_ATTN_QR(96, false);
@@ -397,6 +406,7 @@ int attention_qkv(const bf16_t* q, int q_ld, int seq_q, const bf16_t* qkv, int l
   }
 #undef CACO_ATTN_QR
 #undef CACO_ATTN
+#undef CACO_ATTN_
   return check_hip(hipGetLastError(), "attention launch");
 }
 

@@ -23,6 +23,9 @@
 // Reference ops replaced: as gemm_w8.hip.
 // a kernel that has not run on hardware yet: the intra-wave LDS hand-offs are also fenced for the compiler (common.h)
 #define CACO_WAVE_SYNC_FENCE 1
+#ifndef WAVESIM
+#define W8_EPI_SLAB_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #include "common.h"
 #include "kernels.h"
 #include "gemm_w8_common.h"
@@ -190,8 +193,15 @@ __device__ __forceinline__ void q16_body(const GemmArgs& p, char* smem) {
     const int64_t m_cur = (int64_t)tm_ * 256;
     const int n_cur = tn_ * 256;
     // the epilogue of gemm_w8 handles a 128 x 64 part: once per 64-column half, through this wave's 4 KiB of the free A slot
+    // everything the epilogue derives from the lane index (row / chunk numbers, per-lane offsets) is loop-invariant over the
+    // output tiles; carried through the K-loop it overflows the 256 VGPRs next to the 96 fragment registers (25-40 dwords
+    // spilled before the loop and reloaded per tile).  An opaque copy of the lane index per epilogue makes it epilogue-local.
+    int lane_e = lane;
+#ifndef WAVESIM
+    asm volatile("" : "+v"(lane_e));
+#endif
 #pragma unroll
-    for (int h = 0; h < 2; ++h) w16_epilogue<EPI, ACT, MODE>(acc[h], p, m_cur, n_cur, wm, wn * 2 + h, lane, smem + a_2 + wave * 4096);
+    for (int h = 0; h < 2; ++h) w16_epilogue<EPI, ACT, MODE>(acc[h], p, m_cur, n_cur, wm, wn * 2 + h, lane_e, smem + a_2 + wave * 4096);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // nobody may DMA into the slab slot while another wave still transposes through it
 #pragma unroll

@@ -65,6 +65,12 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 // the compiler hoists all 16 of them out of the tile loop and carries 14 more VGPRs through the K-loop (238 -> 252 of the
 // 256 a two-waves-per-SIMD kernel has).  Making the row pitch opaque once per epilogue keeps them epilogue-local: one
 // v_add with a scalar operand per access instead.
+// W8_EPI_SLAB_FENCE(): a scheduling fence between the slabs of an epilogue.  Empty for gemm_w8 (its instruction streams are
+// the hardware-verified ones).  gemm_w4q defines it as sched_barrier: its 256 accumulators live in AGPRs and, left free, the
+// scheduler hoists the v_accvgpr_reads of later slabs over the current one until the 256 VGPRs overflow (18-40 spilled).
+#ifndef W8_EPI_SLAB_FENCE
+#define W8_EPI_SLAB_FENCE() ((void)0)
+#endif
 #ifdef WAVESIM
 #define W8_EPI_LOCAL(x) ((void)0)
 #else
@@ -89,6 +95,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
     const float* c1_l = fold ? p.fold_c1 + nw + lq * 4 : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      W8_EPI_SLAB_FENCE();
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib) {
         float nmr = 0.f, rstd = 1.f;                 // out = rstd * acc + (-mean * rstd) * c1 + bias
@@ -182,6 +189,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int i = s >> 1, j = s & 1;
+      W8_EPI_SLAB_FENCE();
       if (has_resid && s + RA < 8) fetch(s + RA, res[(s + RA) % RN]);
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)

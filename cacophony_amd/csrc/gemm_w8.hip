@@ -23,7 +23,7 @@
 //   schedule  persistent; XCD x owns a contiguous run of tiles (n fastest), so the tiles that share an A row panel
 //             run together on one XCD's L2
 //
-// Anatomy (32x32x16 form, tools/w8_timing.py): per 256x256 tile at K = 768 the K-loop takes ~28 k cycles,
+// Anatomy (measured on the 32x32x16 form in round 2, tools/w8_timing.py): per 256x256 tile at K = 768 the K-loop takes ~28 k cycles,
 // the epilogue 9.7 k (bf16) .. 11.6 k (SiLU) .. 44 k (fp32 + residual) with the matrix pipe idle; the epilogue is bound by
 // the CU's own issue / store path, not by HBM.  Ablation builds: -DW4_NOEPI, -DW4_NODMA, -DW4_NOREADS
 // (tools/build_variant.sh, tools/energy_ab.sh).  Retired siblings: the 32x32x16 form of this kernel with its timing stamps

@@ -2,9 +2,11 @@
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
 #   bash tools/gpu_session.sh all                                    everything in one call (~60 min)
-# 1. hardware truth for the DEFAULT build: pytest -m gpu, smoke, bench  -> gpurun_out/r3_v0/   (copy to profiles/r3_v0/)
-# 2. A/B inside the step, one box, interleaved: default | CACO_ATTN_SMALL=1 | CACO_POS_FUSE=1 | CACO_POOL_FUSE=1 | all three | CACO_W_NGROUP=0
-# 3. rocprofv3 kernel stats of the default build and of the build with both switches on
+# 1. truth: hardware record of the DEFAULT build: pytest -m gpu (default path), the experimental cases apart, smoke, bench,
+#    rocprofv3 kernel stats  -> gpurun_out/r4_v0/   (copy to profiles/r4_v0/)
+# 2. ab: every run-time switch against the default, interleaved in one process (tools/ab_switches.py: flip / delete verdicts),
+#    rocprofv3 kernel stats with the fusions on, GEMM kernels per shape (w8 / w4q / w4h / x / 128), fc1 inside chains
+# 3. variants: compile-time A/B libraries (tools/r3_build_variants.sh)      4. pmc: SQ / TCC counters, HBM traffic of fc1
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}
@@ -25,34 +27,11 @@ head -c 600 "$OUT/bench.json"; echo
 bash tools/profile_bench.sh r4_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
 cp gpurun_out/prof_r4_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 fi
-ab() {   # name, env assignments...
-  local name=$1; shift
-  env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 20 --warmup 5 2>/dev/null | python -c "
-import json,sys
-try:
-    d=json.loads(sys.stdin.read()); s=d['stages']
-    keys=('audio.gemm_fc1','audio.gemm_qkv','audio.gemm_fc2','audio.gemm_out','audio.attention','audio.ln','audio.pos_embed','audio.patch_embed','text.attention')
-    print('$name', d['ms_per_step'], d['outputs_finite'], {k: round(s[k]['ms_per_step'],3) for k in keys if k in s})
-except Exception as e:
-    print('$name', 'FAILED', repr(e))"
-}
 if want ab; then
-{
-for rep in 1 2; do
-  ab default       CACO_DUMMY=0
-  ab attn_small    CACO_ATTN_SMALL=1
-  ab pos_fuse      CACO_POS_FUSE=1
-  ab pool_fuse     CACO_POOL_FUSE=1
-  ab all3          CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1
-  ab ln_fold       CACO_LN_FOLD=1              # round 2: a wash; its epilogues lost their 32 spilled SGPRs with the round-3 epilogue change
-  ab ngroup_off    CACO_W_NGROUP=0
-  ab pingpong      CACO_PINGPONG=1             # consecutive kernels walk the rows in opposite directions (one n-tile group): compare with ngroup_off
-  ab text_w4h      CACO_W4H_MAX_TILES=128      # the text tower's N = 768 GEMMs (96 tiles of 256 x 256) on 128 x 256 tiles (gemm_w4h.hip)
-  ab text_n768_128 CACO_W8_MIN_TILES=200      # the text tower's N = 768 GEMMs (192 tile units) on the 128 x 128 kernel instead of w8
-done
-} | tee "$OUT/ab.txt"
-CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r3_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
-cp gpurun_out/prof_r3_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
+# every run-time switch against the default, interleaved inside ONE process (caco_set_switch), with the flip / delete verdict
+(timeout 900 python tools/ab_switches.py --reps 5 --steps 10 --out "$OUT/ab_switches.json" 2>&1 | tail -40) | tee "$OUT/ab_switches.txt"
+CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r4_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
+cp gpurun_out/prof_r4_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
   for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Rebuild the A/B variant libraries of the round-3 GPU session from the CURRENT sources (they travel with gpurun: in-tree,
-# git-ignored).  Run after any kernel change, before `gpurun -- bash tools/r3_gpu_session.sh`.
+# Rebuild the A/B variant libraries of the GPU session (tools/gpu_session.sh variants) from the CURRENT sources (they travel with gpurun: in-tree,
+# git-ignored).  Run after any kernel change, before `gpurun -- bash tools/gpu_session.sh variants`.
 set -e
 cd "$(dirname "$0")/.."
 rm -f cacophony_amd/_variants/*.so cacophony_amd/_variants/*.o
@@ -19,6 +19,11 @@ bash tools/build_variant.sh a_sc1 gemm_w8.hip -DW8_A_AUX=16
 # epilogue stores with the default cache policy (instead of nt / sc1): for the ping-pong experiment, in case the streaming
 # hints keep a producer's output out of the Infinity Cache
 bash tools/build_variant.sh st_plain gemm_w8.hip -DW8_ST_AUX=0 -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
+# round 4: the plain fp32 epilogues (out-proj, fc2, patch-embed) straight from the accumulator layout - no LDS transposition,
+# 12 resp. 16 residual blocks in flight per wave (gemm_w8_epilogue.h W8_F32_DIRECT); checked on the simulator build
+bash tools/build_variant.sh f32direct gemm_w8.hip -DW8_F32_DIRECT=12
+bash tools/build_variant.sh f32direct16 gemm_w8.hip -DW8_F32_DIRECT=16
+bash tools/build_variant.sh f32direct4 gemm_w8.hip -DW8_F32_DIRECT=4
 python -m cacophony_amd.build --force >/dev/null
 # every variant must resolve all its symbols (a kernel-side signature change breaks the parked attention variant silently otherwise)
 python - <<'PY'

@@ -6,7 +6,7 @@
 #    rocprofv3 kernel stats  -> gpurun_out/r4_v0/   (copy to profiles/r4_v0/)
 # 2. ab: every run-time switch against the default, interleaved in one process (tools/ab_switches.py: flip / delete verdicts),
 #    rocprofv3 kernel stats with the fusions on, GEMM kernels per shape (w8 / w4q / w4h / x / 128), fc1 inside chains
-# 3. variants: compile-time A/B libraries (tools/r3_build_variants.sh)      4. pmc: SQ / TCC counters, HBM traffic of fc1
+# 3. variants: compile-time A/B libraries (tools/build_variants.sh)      4. pmc: SQ / TCC counters, HBM traffic of fc1
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}
@@ -36,11 +36,14 @@ cp gpurun_out/prof_r4_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switc
   for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
 fi
-# compile-time variants prepared by tools/r3_build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
+# compile-time variants prepared by tools/build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
 if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
-  (CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
+  # a variant library under the product's own op tests (CACO_ALLOW_VARIANT_LIB: the suite otherwise refuses any library but the product's)
+  (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
   cat "$OUT/pytest_fastpass.txt"
-  (timeout 1500 bash tools/ab_bench.sh 2 default fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
+  (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_f32direct.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or guard" 2>&1 | tail -3) > "$OUT/pytest_f32direct.txt"
+  cat "$OUT/pytest_f32direct.txt"
+  (timeout 1500 bash tools/ab_bench.sh 2 default f32direct f32direct16 f32direct4 fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
   cat "$OUT/ab_variants.txt"
   (CACO_PINGPONG=1 timeout 600 bash tools/ab_bench.sh 2 default st_plain ln_nt a_nt) > "$OUT/ab_variants_pingpong.txt" 2>&1     # ping-pong x store policy
   cat "$OUT/ab_variants_pingpong.txt"

@@ -55,6 +55,11 @@ namespace {
   _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
   _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
     acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[(IB) * 4 + q_][j_], 0, 0, 0);
+// the same with C = 0 (inline constant): the first touch of an accumulator block in an output tile (-DW8_ZERO_C)
+#define W16_MFMAS_Z(XC, WC, IB)                                                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
+    acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 // interleave of one phase: 16 MFMAs, the first NRD of them followed by a fragment read, VMEM after the MFMAs in VM_MASK
 #define W16_SCHED(NRD, VM_MASK)                                                                             \
   _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                       \
@@ -135,62 +140,36 @@ __device__ __forceinline__ void w16_body(const GemmArgs& p, char* smem) {
   int c_li = slot;
   while (true) {
     f32x4 acc[8][4];
+#ifndef W8_ZERO_C
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+#endif
 
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* xs = smem + a_c + x_off;
-      const char* ws = smem + w_c + w_off;
-      // P0
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W16_RD(xb[i], W16_F(xs, 4 + i, 0))
-      W16_RD(wn_[0], W16_F(ws, 0, 1))
-      W16_RD(wn_[1], W16_F(ws, 1, 1))
-      W16_MFMAS(xa, wc, 0)
-      W16_SCHED(6, 0)
-      // P1
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W16_RD(xa[i], W16_F(xs, i, 1))
-      W16_RD(wn_[2], W16_F(ws, 2, 1))
-      W16_RD(wn_[3], W16_F(ws, 3, 1))
-      w4_piece_a<8>(CA, 0, smem + a_2, wave);
-      w4_piece_a<8>(CA, 1, smem + a_2, wave);
-      W16_MFMAS(xb, wc, 1)
-      W16_SCHED(6, (1 << 4) | (1 << 10))
-      // P2
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W16_RD(xb[i], W16_F(xs, 4 + i, 1))
-      w4_piece_a<8>(CA, 2, smem + a_2, wave);
-      w4_piece_a<8>(CA, 3, smem + a_2, wave);
-      W16_MFMAS(xa, wn_, 0)
-      W16_SCHED(4, (1 << 4) | (1 << 10))
-      advance_a();
-      if (stores_pending) {
-        if (EPI == EPI_F32 && p.xb_out) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
-        stores_pending = false;
-      } else {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // P3
-#pragma unroll
-      for (int i = 0; i < 4; ++i) W16_RD(xa[i], W16_F(smem + a_1 + x_off, i, 0))
-#pragma unroll
-      for (int j = 0; j < 4; ++j) W16_RD(wc[j], W16_F(smem + w_1 + w_off, j, 0))
-#pragma unroll
-      for (int it = 0; it < 4; ++it) w4_piece_w<8>(CW, it, ldw, smem + w_c, wave);
-      W16_MFMAS(xb, wn_, 1)
-      W16_SCHED(8, (1 << 2) | (1 << 6) | (1 << 10) | (1 << 14))
-      advance_w();
-      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
-      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+#ifdef W8_ZERO_C
+    // EXPERIMENT (round 4, variant build, never the default): the first K-tile's first-touch MFMAs take C = 0 as an inline
+    // constant instead of reading accumulators that 128 v_mov per wave and tile zeroed (issue slots next to an issue-bound
+    // bf16 epilogue: ~1.5 k of the ~38 k cycles of a QKV / fc1 tile by the static count, profiles/r4_cpu/epilogue_budget.txt)
+    {
+#define W16_MF_FIRST W16_MFMAS_Z
+#include "gemm_w8_ktile.inc"
+#undef W16_MF_FIRST
     }
+    for (int kt = 1; kt < nk; ++kt) {
+#define W16_MF_FIRST W16_MFMAS
+#include "gemm_w8_ktile.inc"
+#undef W16_MF_FIRST
+    }
+#else
+    for (int kt = 0; kt < nk; ++kt) {
+#define W16_MF_FIRST W16_MFMAS
+#include "gemm_w8_ktile.inc"
+#undef W16_MF_FIRST
+    }
+#endif
     const int t = base + c_li;
     int tm_, tn_;
     w4_decode(t, tiles_n, tiles_m, p.ngroup, tm_, tn_);

@@ -130,11 +130,31 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
               o[r + 1] = (bf16_t)y[1];
             }
           } else {
+#ifdef W8_PK_EPI
+            // EXPERIMENT (round 4, variant build): the same arithmetic written on register pairs.  Left to the scalar loop
+            // below, hipcc 7.2 turns the bias-only epilogue (QKV) into 64 v_add + 64 v_pk_add + 96 v_cvt_pk + 96 permute /
+            // align / pk_mov = 320 VALU per wave and tile where 64 v_pk_add + 64 v_cvt_pk do the work (static count,
+            // profiles/r4_cpu/epilogue_budget.txt); the epilogue is issue-bound.  Bit-identical results.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              f32x2 x;
+              if constexpr (MODE == 1) {
+                x = f32x2{a[r], a[r + 1]} + f32x2{bb[r], bb[r + 1]};
+              } else {
+                x[0] = __builtin_fmaf(a[r], rstd, bb[r]);
+                x[1] = __builtin_fmaf(a[r + 1], rstd, bb[r + 1]);
+              }
+              o[r] = (bf16_t)w4_epi_act<ACT>(x[0]);
+              o[r + 1] = (bf16_t)w4_epi_act<ACT>(x[1]);
+            }
+#else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float x = MODE == 1 ? a[r] + bb[r] : __builtin_fmaf(a[r], rstd, bb[r]);
               o[r] = (bf16_t)w4_epi_act<ACT>(x);
             }
+#endif
           }
           *reinterpret_cast<bf16x4*>(slab + row * 128 + (((jb * 2 + (lq >> 1)) ^ ((row >> 1) & 7)) << 4) + (lq & 1) * 8) = o;
         }

@@ -103,3 +103,36 @@ def test_integration_doc_struct_matches_header_and_binding():
     assert [(n, "float" if t is C.c_float else "int32_t") for n, t in _lib.CacoConfigC._fields_] == header_fields
     lib = _lib.load()
     assert lib.caco_config_size() == C.sizeof(ns["caco_config"]) == C.sizeof(_lib.CacoConfigC) == 4 * len(header_fields)
+
+
+def test_run_time_switches_read_their_environment_once_then_only_the_api(tmp_path):
+    """caco_set_switch / caco_get_switch (host-only, no GPU needed): defaults, round trip, the context manager restores,
+    unknown names are status codes, and the environment is the INITIAL value only - a later change of the variable is not
+    seen (no launch path calls getenv), a later caco_set_switch is."""
+    import subprocess
+    import sys
+    lib = _lib.load()
+    assert lib.caco_get_switch(b"CACO_NO_SUCH_SWITCH") == -2 ** 31
+    assert lib.caco_set_switch(b"CACO_NO_SUCH_SWITCH", 1) == _lib.CACO_ERR_INVALID and b"unknown switch" in lib.caco_last_error()
+    assert lib.caco_set_switch(None, 1) == _lib.CACO_ERR_INVALID
+    prev = lib.caco_get_switch(b"CACO_POS_FUSE")
+    with _lib.switch("CACO_POS_FUSE", 1 - prev):
+        assert lib.caco_get_switch(b"CACO_POS_FUSE") == 1 - prev
+    assert lib.caco_get_switch(b"CACO_POS_FUSE") == prev
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "from cacophony_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "g = lambda n: lib.caco_get_switch(n.encode())\n"
+        "first = [g(n) for n in ('CACO_PINGPONG', 'CACO_W_NGROUP', 'CACO_ATTN_ROWS', 'CACO_W8_MIN_TILES', 'CACO_POOL_FUSE')]\n"
+        "os.environ['CACO_PINGPONG'] = '0'; os.environ['CACO_POOL_FUSE'] = '1'\n"      # after first use: must not be seen
+        "later = [g('CACO_PINGPONG'), g('CACO_POOL_FUSE')]\n"
+        "lib.caco_set_switch(b'CACO_PINGPONG', 0)\n"
+        "print(first, later, g('CACO_PINGPONG'))\n" % root)
+    env = dict(os.environ, CACO_PINGPONG="1", CACO_W_NGROUP="2")
+    for k in ("CACO_ATTN_ROWS", "CACO_W8_MIN_TILES", "CACO_POOL_FUSE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "[1, 2, 64, 128, 0] [1, 0] 0"

@@ -79,6 +79,17 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         flags = flags + ["-DWAVESIM_TSAN"]
     tag = ("." + tag if tag else "") + (".asan" if asan else "") + (".tsan" if tsan else "")
 
+    # textually included kernel pieces (csrc/*.inc) get the same translation; the copy in _gen/ is found first by the
+    # quote-include of the generated source next to it
+    for inc in sorted(f for f in os.listdir(CSRC) if f.endswith(".inc")):
+        with open(os.path.join(CSRC, inc)) as f:
+            t = translate(f.read())
+        dst = os.path.join(GEN, inc)
+        if not os.path.exists(dst) or open(dst).read() != t:
+            with open(dst, "w") as f:
+                f.write(t)
+    headers = headers + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
+
     def one(src):
         path = src if os.path.isabs(src) else os.path.join(CSRC, src)
         base = os.path.basename(path)

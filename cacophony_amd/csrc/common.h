@@ -68,7 +68,36 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each): the result is rounded to bf16 right after
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(z) for the erf-GELU of the text stack (F.gelu, exact form: text_models/roberta.py:150-158), branch-free:
+// z clamped to [-4, 4] (erf(4) = 1 - 1.5e-8), erf(z) = z P(z^2) / Q(z^2) with the degree-6 / degree-4 minimax pair that
+// Eigen / XLA use for fp32 erf.  Checked against scipy.special.erf on 2e6 points of [-6, 6] (tests/test_oracle_golden.py):
+// |error| <= 4.5e-7 absolute, <= 2.7e-7 relative for |z| < 1; GELU built on it differs from torch's by <= 1.5e-6 absolute,
+// i.e. by less than 1/1000 of the bf16 rounding the activation gets right afterwards.  The device library's erff is a
+// two-branch routine (|z| < 1 polynomial, else exp): on 128 independent values per lane both branches run with the lanes
+// masked, 5 500 instructions per wave and output tile in the persistent GEMM's epilogue against its 3 600-instruction K-loop
+// (profiles/r4_cpu/epilogue_budget.txt).  This form is 17 VALU + 1 v_rcp per value.  Every GEMM kernel uses this one function,
+// so a caption's embedding does not depend on which tile shape its batch size selected.
+__device__ __forceinline__ float erf_rational_f(float z) {
+  z = fminf(fmaxf(z, -4.0f), 4.0f);
+  const float z2 = z * z;
+  float p = -2.72614225801306e-10f;
+  p = __builtin_fmaf(p, z2, 2.77068142495902e-08f);
+  p = __builtin_fmaf(p, z2, -2.10102402082508e-06f);
+  p = __builtin_fmaf(p, z2, -5.69250639462346e-05f);
+  p = __builtin_fmaf(p, z2, -7.34990630326855e-04f);
+  p = __builtin_fmaf(p, z2, -2.95459980854025e-03f);
+  p = __builtin_fmaf(p, z2, -1.60960333262415e-02f);
+  float q = -1.45660718464996e-05f;
+  q = __builtin_fmaf(q, z2, -2.13374055278905e-04f);
+  q = __builtin_fmaf(q, z2, -1.68282697438203e-03f);
+  q = __builtin_fmaf(q, z2, -7.37332916720468e-03f);
+  q = __builtin_fmaf(q, z2, -1.42647390514189e-02f);
+  return (z * p) * __builtin_amdgcn_rcpf(q);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float h = 0.5f * x;
+  return __builtin_fmaf(h, erf_rational_f(x * 0.70710678118654752440f), h);
+}
 
 // host: fp32 -> bf16 round-to-nearest-even
 static inline uint16_t f32_to_bf16_host(float f) {

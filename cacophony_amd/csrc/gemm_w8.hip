@@ -55,7 +55,7 @@ namespace {
   _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
   _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
     acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[(IB) * 4 + q_][j_], 0, 0, 0);
-// the same with C = 0 (inline constant): the first touch of an accumulator block in an output tile (-DW8_ZERO_C)
+// the same with C = 0 (inline constant): the first touch of an accumulator block in an output tile
 #define W16_MFMAS_Z(XC, WC, IB)                                                                             \
   _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
   _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
@@ -140,7 +140,7 @@ __device__ __forceinline__ void w16_body(const GemmArgs& p, char* smem) {
   int c_li = slot;
   while (true) {
     f32x4 acc[8][4];
-#ifndef W8_ZERO_C
+#ifdef W8_CLASSIC
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -149,10 +149,13 @@ __device__ __forceinline__ void w16_body(const GemmArgs& p, char* smem) {
         for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 #endif
 
-#ifdef W8_ZERO_C
-    // EXPERIMENT (round 4, variant build, never the default): the first K-tile's first-touch MFMAs take C = 0 as an inline
-    // constant instead of reading accumulators that 128 v_mov per wave and tile zeroed (issue slots next to an issue-bound
-    // bf16 epilogue: ~1.5 k of the ~38 k cycles of a QKV / fc1 tile by the static count, profiles/r4_cpu/epilogue_budget.txt)
+#ifndef W8_CLASSIC
+    // The first K-tile of an output tile is peeled: its first-touch MFMAs take C = 0 as an inline constant, so the accumulators
+    // are never zeroed by VALU moves.  Left as one loop over zero-initialised accumulators, hipcc 7.2 emits 128 v_mov for the
+    // zeroing plus 128 more at the tile-loop header (loop-carried copies) per wave and output tile in the bf16-epilogue kernels
+    // - 268 instructions next to an issue-bound epilogue (profiles/r4_cpu/epilogue_budget.txt; for the fp32-epilogue kernels it
+    // peels by itself).  Default since round 4 on the static count and bitwise-equal simulator results; NOT yet timed: the
+    // variant build `classic` (-DW8_CLASSIC: one loop, scalar bias epilogue) is the other arm of the A/B (tools/gpu_session.sh).
     {
 #define W16_MF_FIRST W16_MFMAS_Z
 #include "gemm_w8_ktile.inc"

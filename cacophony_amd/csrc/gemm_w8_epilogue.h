@@ -130,11 +130,12 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
               o[r + 1] = (bf16_t)y[1];
             }
           } else {
-#ifdef W8_PK_EPI
-            // EXPERIMENT (round 4, variant build): the same arithmetic written on register pairs.  Left to the scalar loop
-            // below, hipcc 7.2 turns the bias-only epilogue (QKV) into 64 v_add + 64 v_pk_add + 96 v_cvt_pk + 96 permute /
-            // align / pk_mov = 320 VALU per wave and tile where 64 v_pk_add + 64 v_cvt_pk do the work (static count,
-            // profiles/r4_cpu/epilogue_budget.txt); the epilogue is issue-bound.  Bit-identical results.
+#ifndef W8_CLASSIC
+            // Written on register pairs like the SiLU branch.  Left to the scalar loop below, hipcc 7.2 turns the bias-only
+            // epilogue (QKV) into 64 v_add + 64 v_pk_add + 96 v_cvt_pk + 96 permute / align / pk_mov = 320 VALU per wave and
+            // tile where 64 v_pk_add + 64 v_cvt_pk do the work (static count, profiles/r4_cpu/epilogue_budget.txt); the epilogue
+            // is issue-bound.  Bit-identical results.  Default since round 4, not yet timed: -DW8_CLASSIC
+            // (variant build `classic`) is the scalar form.
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {

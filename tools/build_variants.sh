@@ -24,12 +24,10 @@ bash tools/build_variant.sh st_plain gemm_w8.hip -DW8_ST_AUX=0 -DW8_ST_AUX_F32=0
 bash tools/build_variant.sh f32direct gemm_w8.hip -DW8_F32_DIRECT=12
 bash tools/build_variant.sh f32direct16 gemm_w8.hip -DW8_F32_DIRECT=16
 bash tools/build_variant.sh f32direct4 gemm_w8.hip -DW8_F32_DIRECT=4
-# round 4, from the static instruction budget (profiles/r4_cpu/epilogue_budget.txt): first K-tile with C = 0 instead of 256 v_mov
-# per wave and tile; the bias-only bf16 epilogue on register pairs; both.  Bitwise the default's results on the simulator.
-bash tools/build_variant.sh zeroc gemm_w8.hip -DW8_ZERO_C
-bash tools/build_variant.sh pkepi gemm_w8.hip -DW8_PK_EPI
-bash tools/build_variant.sh lean gemm_w8.hip -DW8_ZERO_C -DW8_PK_EPI
-bash tools/build_variant.sh lean_f32direct gemm_w8.hip -DW8_ZERO_C -DW8_PK_EPI -DW8_F32_DIRECT=12
+# round 4: the static instruction budget (profiles/r4_cpu/epilogue_budget.txt) made two forms the default WITHOUT a timing - the peeled
+# first K-tile with C = 0 and the bias-only bf16 epilogue on register pairs.  `classic` is the previous form: the other arm of the A/B.
+bash tools/build_variant.sh classic gemm_w8.hip -DW8_CLASSIC
+bash tools/build_variant.sh classic_f32direct gemm_w8.hip -DW8_CLASSIC -DW8_F32_DIRECT=12
 python -m cacophony_amd.build --force >/dev/null
 # every variant must resolve all its symbols (a kernel-side signature change breaks the parked attention variant silently otherwise)
 python - <<'PY'

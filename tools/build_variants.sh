@@ -9,6 +9,10 @@ cp cacophony_amd/csrc/attention.hip /tmp/_attention_saved.hip
 tail -n +10 tools/experimental/attention_fastpass.hip > cacophony_amd/csrc/attention.hip
 bash tools/build_variant.sh fastpass attention.hip -DATTN_FAST_PASS || true
 cp /tmp/_attention_saved.hip cacophony_amd/csrc/attention.hip
+# round 4: K fragment reads of the score phase pinned 1 / 2 steps ahead of their MFMAs (the default build's ISA waits lgkmcnt(0) after
+# every read there: one fragment buffer at 256 VGPRs); same registers, same results (simulator)
+bash tools/build_variant.sh kpipe1 attention.hip -DATTN_KPIPE=1
+bash tools/build_variant.sh kpipe2 attention.hip -DATTN_KPIPE=2
 bash tools/build_variant.sh attn_nt attention.hip -DATTN_ST_AUX=2
 bash tools/build_variant.sh attn_sc1 attention.hip -DATTN_ST_AUX=16
 bash tools/build_variant.sh ln_nt norm.hip -DLN_ST_NT

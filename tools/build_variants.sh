@@ -30,6 +30,11 @@ bash tools/build_variant.sh f32direct16 gemm_w8.hip -DW8_F32_DIRECT=16
 bash tools/build_variant.sh f32direct4 gemm_w8.hip -DW8_F32_DIRECT=4
 # round 4: the static instruction budget (profiles/r4_cpu/epilogue_budget.txt) made two forms the default WITHOUT a timing - the peeled
 # first K-tile with C = 0 and the bias-only bf16 epilogue on register pairs.  `classic` is the previous form: the other arm of the A/B.
+# fp32 epilogue stores with the default (write-back) policy: on gfx950's in-order vmcnt queue the next tile's operand loads cannot be
+# confirmed before the epilogue's stores are acknowledged; a store acknowledged at the L2 instead of at memory shortens that wait
+# (profiles/r4_cpu/epilogue_budget.txt).  Round 2 compared nt and sc1 for this epilogue, not the default policy.
+bash tools/build_variant.sh f32_wb gemm_w8.hip -DW8_ST_AUX_F32=0
+bash tools/build_variant.sh f32_wb_ld0 gemm_w8.hip -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
 bash tools/build_variant.sh classic gemm_w8.hip -DW8_CLASSIC
 bash tools/build_variant.sh classic_f32direct gemm_w8.hip -DW8_CLASSIC -DW8_F32_DIRECT=12
 python -m cacophony_amd.build --force >/dev/null

@@ -43,7 +43,7 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/nul
   cat "$OUT/pytest_fastpass.txt"
   (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_f32direct.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or guard" 2>&1 | tail -3) > "$OUT/pytest_f32direct.txt"
   cat "$OUT/pytest_f32direct.txt"
-  (timeout 2400 bash tools/ab_bench.sh 2 default classic f32direct f32direct16 f32direct4 kpipe1 kpipe2 fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
+  (timeout 2400 bash tools/ab_bench.sh 2 default classic f32_wb f32_wb_ld0 f32direct f32direct16 f32direct4 kpipe1 kpipe2 fastpass attn_nt attn_sc1 ln_nt ln_2rows a_nt w_nt a_sc1) > "$OUT/ab_variants.txt" 2>&1
   cat "$OUT/ab_variants.txt"
   (CACO_PINGPONG=1 timeout 600 bash tools/ab_bench.sh 2 default st_plain ln_nt a_nt) > "$OUT/ab_variants_pingpong.txt" 2>&1     # ping-pong x store policy
   cat "$OUT/ab_variants_pingpong.txt"

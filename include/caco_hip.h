@@ -21,8 +21,8 @@
  *   - a caco_model lives on the device that was current at caco_create(); every entry point that takes a model returns
  *     CACO_ERR_STATE when another device is current (kernel attributes, CU counts and the mel tables are kept per device,
  *     so several models on several GPUs of one process are fine).
- *   - process-global state: the two tuning knobs caco_set_gemm_tile / caco_set_ln_fold (the latter only as the default of
- *     NEW models; caco_model_set_ln_fold acts on one model) and the caco_profile_* recorder (mutex-guarded).
+ *   - process-global state: the tuning knobs caco_set_gemm_tile / caco_set_switch / caco_set_ln_fold (the last only as the
+ *     default of NEW models; caco_model_set_ln_fold acts on one model) and the caco_profile_* recorder (mutex-guarded).
  *   - row-major everywhere; Linear weights arrive in torch layout [out, in], fp32.
  */
 #ifndef CACO_HIP_H

@@ -136,3 +136,35 @@ def test_run_time_switches_read_their_environment_once_then_only_the_api(tmp_pat
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "[1, 2, 64, 128, 0] [1, 0] 0"
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """include/caco_hip.h compiled as C99 (-pedantic, warnings as errors) and linked against the library from a C program that
+    calls the host-only entry points: the boundary is a C ABI, not a C++ one."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "caco_hip.h"\n'
+        "int main(void) {\n"
+        "  caco_config cfg;\n"
+        "  caco_default_config(&cfg);\n"
+        '  printf("%d %d %d %d %d\\n", (int)caco_config_size(), (int)sizeof(cfg), (int)cfg.audio_hidden, (int)cfg.text_vocab,\n'
+        '         (int)caco_get_switch("CACO_ATTN_ROWS"));\n'
+        "  if (caco_create(NULL, NULL) == 0) return 2;            /* a null config is a status code, not a crash */\n"
+        '  printf("%s\\n", caco_last_error());\n'
+        "  return caco_mel_num_frames(160000) == 1000 ? 0 : 3;\n"
+        "}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.join(root, "cacophony_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        os.path.join(libdir, "libcaco_hip.so"), f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ)
+    env.pop("CACO_ATTN_ROWS", None)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    assert r.stdout.splitlines()[0] == "88 88 768 50265 64" and "null" in r.stdout.splitlines()[1]

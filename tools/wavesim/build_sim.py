@@ -9,6 +9,8 @@ Source translation (the only edits made to a kernel source; everything else is t
   * `asm volatile("s_waitcnt vmcnt(%0) ..." :: "n"(E) ...)` -> wavesim::s_waitcnt_n("...", E)
   * `extern __shared__ ... T NAME[];`                       -> T* NAME = (T*)wavesim::dyn_lds();
   * `__attribute__((amdgpu_...(...)))` on kernels           -> dropped (occupancy hints)
+Textually included kernel pieces (`csrc/*.inc`, e.g. the K-tile body of gemm_w8) get the same translation; the translated copy is
+written next to the generated source, where the quote-include finds it first.
 """
 from __future__ import annotations
 

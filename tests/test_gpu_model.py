@@ -620,3 +620,36 @@ def test_tower_outputs_keep_their_guard_rows(tiny_model):
     torch.cuda.synchronize()
     assert intact(emb_f, B) and intact(hid_f, B * T)
     assert torch.isfinite(emb).all() and torch.isfinite(hid).all()
+
+
+@pytest.mark.experimental
+def test_step_is_capturable_as_a_hip_graph(tiny_model):
+    """The whole step (both towers on their streams + similarity) records into a HIP graph once the arenas are warm - no
+    allocation, no host synchronisation, no environment read on any launch path - and a replay reproduces the eager result
+    bitwise.  (tools/graph_probe.py measured no gain at batch 256: the step is not launch-bound there; small batches are.)
+    Marked experimental: written in round 4 without a GPU, never run."""
+    m = tiny_model
+    wav = torch.from_numpy(synth.make_waveforms(3)).to(DEV)
+    ids, mask = synth.make_captions(3, 32, m.text_config.vocab_size)
+    ids, mask = torch.as_tensor(ids).to(DEV), torch.as_tensor(mask).to(DEV)
+    out = torch.empty(3, 3, device=DEV)
+
+    def step():
+        bank = m.encode_pairs(wav, ids, mask, packed=True)
+        return similarity(bank[:, 0], bank[:, 1], 1.0, out=out)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    eager = out.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        step()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

@@ -365,94 +365,101 @@ def main():
     # ---- per-launch-group timing with HIP events on the launch stream (separate, un-timed pass) -----------------
     stages, roofline, extra = {}, None, None
     if rank == 0 and not DRYRUN:
-        def serial_step():      # per-launch timings need one stream: overlapped launches stretch each other's event pairs
-            ea = model.encode_audio(wav, SEQ)
-            et = model.encode_text(ids, mask, check_ids=False)
-            return similarity(ea, et, 1.0, out=sim_out[:, :B_PER_GPU])
-
-        lib.caco_profile_enable(1)
-        for _ in range(max(1, args.profile_steps)):
-            serial_step()
-        torch.cuda.synchronize()
-        buf = C.create_string_buffer(1 << 16)
-        lib.caco_profile_report(buf, len(buf))
-        lib.caco_profile_enable(0)
-        prof = json.loads(buf.value.decode())
-        fl, by = _flops(B_PER_GPU), _bytes(B_PER_GPU)
-        psteps = max(1, args.profile_steps)
-        for name, rec in sorted(prof.items()):
-            avg_ms = rec["ms"] / rec["n"]
-            ent = {"ms_per_step": round(rec["ms"] / psteps, 4), "launches_per_step": rec["n"] // psteps, "avg_launch_ms": round(avg_ms, 5)}
-            if name in fl:
-                tf = fl[name] / (avg_ms * 1e-3) / 1e12
-                ent.update(bound="mfma", achieved_tflops=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4))
-            elif name in by:
-                gbs = by[name] / (avg_ms * 1e-3) / 1e9
-                ent.update(bound="hbm", achieved_gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
-            stages[name] = ent
-        dom = stages.get("audio.gemm_fc1")
-        # HBM bytes of one fc1 launch: a committed TCC-counter measurement (tools/pmc_hbm.sh), quoted ONLY when it was taken
-        # with the tile order this run uses (its "w_ngroup" field; files without the field predate the n-tile groups and
-        # describe one group).  Anything else would pair this run's time with another schedule's bytes.
-        traffic, traffic_source = None, None
         try:
-            import glob
-            ngroup_now = int(lib.caco_get_switch(b"CACO_W_NGROUP"))
-            for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True):
-                rec = json.load(open(cand))
-                if int(rec.get("w_ngroup", 0)) == ngroup_now:
-                    traffic = int(rec["hbm_bytes"])
-                    traffic_source = (os.path.relpath(cand, REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 "
-                                      "launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
-                    break
-            else:
-                traffic_source = f"no committed hbm_traffic.json was measured with the tile order in force (CACO_W_NGROUP = {ngroup_now})"
-        except Exception:
-            traffic = None
-        # algorithmic bytes of one fc1 launch: A [M,768] bf16 in + W [3072,768] bf16 in + out [M,3072] bf16
-        alg_bytes = B_PER_GPU * SEQ_RUN * H * 2 + I * H * 2 + B_PER_GPU * SEQ_RUN * I * 2
-        if dom:
-            roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [126976,768] x [3072,768]^T)",
-                        "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
-                        "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],
-                        "algorithmic_bytes_per_launch": alg_bytes,
-                        "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
-                        "note": "peak = the nominal dense bf16 MFMA figure of MI355X_MICROARCH.md; what bounds this kernel in "
-                                "practice (package power cap, vendor-library calibration) is DESIGN.md section 4 with the "
-                                "measurements under profiles/"}
+            def serial_step():      # per-launch timings need one stream: overlapped launches stretch each other's event pairs
+                ea = model.encode_audio(wav, SEQ)
+                et = model.encode_text(ids, mask, check_ids=False)
+                return similarity(ea, et, 1.0, out=sim_out[:, :B_PER_GPU])
 
-        if not args.no_extra_configs:
-            extra = {}
-            ms = _timeit(lambda: model.encode_audio(wav, SEQ), 5, torch.cuda.synchronize)
-            tf = _audio_tower_flops(B_PER_GPU) / (ms * 1e-3) / 1e12
-            extra["configs[1] audio encoder only (mel + ViT + pooler), batch 256, bf16"] = {
-                "ms_per_batch": round(ms, 3), "clips_per_s": round(B_PER_GPU / ms * 1e3, 1), "achieved_tflops": round(tf, 1),
-                "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+            lib.caco_profile_enable(1)
+            for _ in range(max(1, args.profile_steps)):
+                serial_step()
+            torch.cuda.synchronize()
+            buf = C.create_string_buffer(1 << 16)
+            lib.caco_profile_report(buf, len(buf))
+            lib.caco_profile_enable(0)
+            prof = json.loads(buf.value.decode())
+            fl, by = _flops(B_PER_GPU), _bytes(B_PER_GPU)
+            psteps = max(1, args.profile_steps)
+            for name, rec in sorted(prof.items()):
+                avg_ms = rec["ms"] / rec["n"]
+                ent = {"ms_per_step": round(rec["ms"] / psteps, 4), "launches_per_step": rec["n"] // psteps, "avg_launch_ms": round(avg_ms, 5)}
+                if name in fl:
+                    tf = fl[name] / (avg_ms * 1e-3) / 1e12
+                    ent.update(bound="mfma", achieved_tflops=round(tf, 1), frac=round(tf / PEAK_BF16_TFLOPS, 4))
+                elif name in by:
+                    gbs = by[name] / (avg_ms * 1e-3) / 1e9
+                    ent.update(bound="hbm", achieved_gbs=round(gbs, 1), frac=round(gbs / PEAK_HBM_GBS, 4))
+                stages[name] = ent
+            dom = stages.get("audio.gemm_fc1")
+            # HBM bytes of one fc1 launch: a committed TCC-counter measurement (tools/pmc_hbm.sh), quoted ONLY when it was taken
+            # with the tile order this run uses (its "w_ngroup" field; files without the field predate the n-tile groups and
+            # describe one group).  Anything else would pair this run's time with another schedule's bytes.
+            traffic, traffic_source = None, None
             try:
-                from cacophony_amd import config as Cfg, synth
-                from cacophony_amd.model import AudioMAE
-                enc = Cfg.default_audio_config()
-                mae = AudioMAE(Cfg.AudioMAEConfig(enc, enc), device=device).load_state_dict(synth.make_audiomae_state(enc, enc))
-                V, R = 100, 396
-                g = torch.Generator().manual_seed(0)
-                x = torch.randn(B_PER_GPU, V, 256, generator=g).to(device)
-                perm = torch.stack([torch.randperm(496, generator=g) for _ in range(B_PER_GPU)])
-                vis, res = perm[:, :V].sort(1).values, perm[:, V:].sort(1).values
-                f = lambda t: t.float().to(device)
-                margs = (x, f(torch.ones(B_PER_GPU, V)), f(vis // 8), f(vis % 8), f(res // 8), f(res % 8), f(torch.ones(B_PER_GPU, R)))
-                ms = _timeit(lambda: mae.forward(*margs), 3, torch.cuda.synchronize)
-                tf = MAE_GFLOP_PER_CLIP * B_PER_GPU / ms
-                extra["configs[4] AudioMAE stage-1 forward (100 visible + 396 restored patches, 12 + 12 layers), batch 256, bf16"] = {
+                import glob
+                ngroup_now = int(lib.caco_get_switch(b"CACO_W_NGROUP"))
+                for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True):
+                    rec = json.load(open(cand))
+                    if int(rec.get("w_ngroup", 0)) == ngroup_now:
+                        traffic = int(rec["hbm_bytes"])
+                        traffic_source = (os.path.relpath(cand, REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 "
+                                          "launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
+                        break
+                else:
+                    traffic_source = f"no committed hbm_traffic.json was measured with the tile order in force (CACO_W_NGROUP = {ngroup_now})"
+            except Exception:
+                traffic = None
+            # algorithmic bytes of one fc1 launch: A [M,768] bf16 in + W [3072,768] bf16 in + out [M,3072] bf16
+            alg_bytes = B_PER_GPU * SEQ_RUN * H * 2 + I * H * 2 + B_PER_GPU * SEQ_RUN * I * 2
+            if dom:
+                roofline = {"kernel": "gemm_bf16_w8_kernel<EPI_BF16, SiLU> (audio MLP fc1: [126976,768] x [3072,768]^T)",
+                            "bound": "mfma", "achieved": dom["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+                            "algorithmic_flops_per_launch": fl["audio.gemm_fc1"], "avg_launch_ms": dom["avg_launch_ms"],
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                            "note": "peak = the nominal dense bf16 MFMA figure of MI355X_MICROARCH.md; what bounds this kernel in "
+                                    "practice (package power cap, vendor-library calibration) is DESIGN.md section 4 with the "
+                                    "measurements under profiles/"}
+
+            if not args.no_extra_configs:
+                extra = {}
+                ms = _timeit(lambda: model.encode_audio(wav, SEQ), 5, torch.cuda.synchronize)
+                tf = _audio_tower_flops(B_PER_GPU) / (ms * 1e-3) / 1e12
+                extra["configs[1] audio encoder only (mel + ViT + pooler), batch 256, bf16"] = {
                     "ms_per_batch": round(ms, 3), "clips_per_s": round(B_PER_GPU / ms * 1e3, 1), "achieved_tflops": round(tf, 1),
                     "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
-                del mae
-            except Exception as e:          # the headline number must not depend on the side measurement
-                extra["configs[4] AudioMAE stage-1 forward"] = {"error": repr(e)}
+                try:
+                    from cacophony_amd import config as Cfg, synth
+                    from cacophony_amd.model import AudioMAE
+                    enc = Cfg.default_audio_config()
+                    mae = AudioMAE(Cfg.AudioMAEConfig(enc, enc), device=device).load_state_dict(synth.make_audiomae_state(enc, enc))
+                    V, R = 100, 396
+                    g = torch.Generator().manual_seed(0)
+                    x = torch.randn(B_PER_GPU, V, 256, generator=g).to(device)
+                    perm = torch.stack([torch.randperm(496, generator=g) for _ in range(B_PER_GPU)])
+                    vis, res = perm[:, :V].sort(1).values, perm[:, V:].sort(1).values
+                    f = lambda t: t.float().to(device)
+                    margs = (x, f(torch.ones(B_PER_GPU, V)), f(vis // 8), f(vis % 8), f(res // 8), f(res % 8), f(torch.ones(B_PER_GPU, R)))
+                    ms = _timeit(lambda: mae.forward(*margs), 3, torch.cuda.synchronize)
+                    tf = MAE_GFLOP_PER_CLIP * B_PER_GPU / ms
+                    extra["configs[4] AudioMAE stage-1 forward (100 visible + 396 restored patches, 12 + 12 layers), batch 256, bf16"] = {
+                        "ms_per_batch": round(ms, 3), "clips_per_s": round(B_PER_GPU / ms * 1e3, 1), "achieved_tflops": round(tf, 1),
+                        "frac_of_mfma_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+                    del mae
+                except Exception as e:          # the headline number must not depend on the side measurement
+                    extra["configs[4] AudioMAE stage-1 forward"] = {"error": repr(e)}
+
+        except Exception as e:      # the timed headline above must not be lost to the un-timed profile pass
+            roofline = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
-        cpu = _cpu_baseline(state)
+        try:
+            cpu = _cpu_baseline(state)
+        except Exception as e:          # the headline number must not be lost to the side measurement (host memory, thread limits ...)
+            cpu = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed", "error": repr(e)}
 
     if rank == 0:
         out = {

@@ -33,6 +33,7 @@ bash tools/build_variant.sh f32direct4 gemm_w8.hip -DW8_F32_DIRECT=4
 # fp32 epilogue stores with the default (write-back) policy: on gfx950's in-order vmcnt queue the next tile's operand loads cannot be
 # confirmed before the epilogue's stores are acknowledged; a store acknowledged at the L2 instead of at memory shortens that wait
 # (profiles/r4_cpu/epilogue_budget.txt).  Round 2 compared nt and sc1 for this epilogue, not the default policy.
+bash tools/build_variant.sh bf16_wb gemm_w8.hip -DW8_ST_AUX=0          # the bf16 epilogue's stores with the default policy (round 1 chose nt over it inside round 1's kernels)
 bash tools/build_variant.sh f32_wb gemm_w8.hip -DW8_ST_AUX_F32=0
 bash tools/build_variant.sh f32_wb_ld0 gemm_w8.hip -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
 bash tools/build_variant.sh classic gemm_w8.hip -DW8_CLASSIC

@@ -118,3 +118,21 @@ def test_attention_resources(attention_asm):
     # per 64-key tile and wave of the two-block kernel: 24 score MFMAs + 24 P.V MFMAs, 64 exponentials
     loop_mfma = sum(1 for b in kernels[audio] for i in b if "v_mfma_f32_32x32x16_bf16" in i)
     assert loop_mfma == 48, loop_mfma
+
+
+def test_no_kernel_of_the_library_spills_beyond_the_known_few(tmp_path_factory):
+    """Every kernel of every translation unit: scratch (= spilled registers) is 0, except the two known cases - the two-block audio
+    attention kernel (8 bytes, outside its loop) and the experimental four-wave GEMM gemm_w4q (<= 128 bytes, outside its K-loop; never a default kernel)."""
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("gemm_w8.hip", "attention.hip", "api.hip"))
+    with ThreadPoolExecutor(4) as ex:
+        texts = list(ex.map(lambda s: _assembly(s, tmp_path_factory), srcs))
+    bad = []
+    for src, text in zip(srcs, texts):
+        _, meta = _kernels(text)
+        assert meta or src in ("api.hip",), f"{src}: no kernels found"
+        for name, m in meta.items():
+            limit = 128 if "gemm_bf16_w4q_kernel" in name else 0
+            if m["scratch"] > limit:
+                bad.append((src, name[:80], m["scratch"]))
+    assert not bad, bad

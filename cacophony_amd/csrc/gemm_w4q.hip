@@ -39,6 +39,11 @@ namespace {
   _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                            \
     acc[j_ >> 2][(IB) * 4 + q_][j_ & 3] =                                                                     \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[j_ >> 2][(IB) * 4 + q_][j_ & 3], 0, 0, 0);
+#define Q16_MFMAS_Z(XC, WC, IB)                                                                               \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                            \
+  _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                            \
+    acc[j_ >> 2][(IB) * 4 + q_][j_ & 3] =                                                                     \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 // interleave of one phase: 32 MFMAs, the first NRD of them followed by a fragment read, VMEM after the MFMAs in VM_MASK
 #define Q16_SCHED(NRD, VM_MASK)                                                                               \
   _Pragma("unroll") for (int n_ = 0; n_ < 32; ++n_) {                                                         \
@@ -117,20 +122,18 @@ __device__ __forceinline__ void q16_body(const GemmArgs& p, char* smem) {
   bool stores_pending = false;
   int c_li = slot;
   while (true) {
-    f32x4 acc[2][8][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[h][i][j][e] = 0.f;
+    f32x4 acc[2][8][4];       // first touched by the peeled K-tile's MFMAs with C = 0: no zeroing
+
+    {
+#define Q16_MF_FIRST Q16_MFMAS_Z
+#include "gemm_w4q_ktile.inc"
+#undef Q16_MF_FIRST
+    }
 #ifndef WAVESIM
     // The 256 accumulators must LIVE in the AGPR half of the register file (only v0..v255 and a0..a255 are addressable; the
     // fragments and addresses need the VGPR half).  Left alone, hipcc 7.2 carries them through the K-loop in VGPRs and
     // copies every MFMA's C operand in and its result out (436 v_accvgpr_write + 212 v_accvgpr_read per K-tile); pinning
-    // each tuple to the "a" class once per output tile makes the loop-carried values AGPRs.
+    // each tuple to the "a" class once per output tile (after the peeled first K-tile defined it) makes the loop-carried values AGPRs.
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -138,54 +141,10 @@ __device__ __forceinline__ void q16_body(const GemmArgs& p, char* smem) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
 #endif
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* xs = smem + a_c + x_off;
-      const char* ws = smem + w_c + w_off;
-      // P0
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xb[i] = Q16_F(xs, 4 + i, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wn_[j] = Q16_F(ws, j, 1);
-      Q16_MFMAS(xa, wc, 0)
-      Q16_SCHED(8, 0u)
-      // P1
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = Q16_F(xs, i, 1);
-#pragma unroll
-      for (int j = 4; j < 8; ++j) wn_[j] = Q16_F(ws, j, 1);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) w4_piece_a<4>(CA, it, smem + a_2, wave);
-      Q16_MFMAS(xb, wc, 1)
-      Q16_SCHED(8, (1u << 4) | (1u << 12) | (1u << 20) | (1u << 28))
-      // P2
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xb[i] = Q16_F(xs, 4 + i, 1);
-#pragma unroll
-      for (int it = 4; it < 8; ++it) w4_piece_a<4>(CA, it, smem + a_2, wave);
-      Q16_MFMAS(xa, wn_, 0)
-      Q16_SCHED(4, (1u << 4) | (1u << 12) | (1u << 20) | (1u << 28))
-      advance_a();
-      if (stores_pending) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAIT_ST) : "memory");
-        stores_pending = false;
-      } else {
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // P3
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = Q16_F(smem + a_1 + x_off, i, 0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wc[j] = Q16_F(smem + w_1 + w_off, j, 0);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
-      Q16_MFMAS(xb, wn_, 1)
-      Q16_SCHED(12, (1u << 2) | (1u << 6) | (1u << 10) | (1u << 14) | (1u << 18) | (1u << 22) | (1u << 26) | (1u << 30))
-      advance_w();
-      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
-      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+    for (int kt = 1; kt < nk; ++kt) {
+#define Q16_MF_FIRST Q16_MFMAS
+#include "gemm_w4q_ktile.inc"
+#undef Q16_MF_FIRST
     }
     const int t = base + c_li;
     int tm_, tn_;

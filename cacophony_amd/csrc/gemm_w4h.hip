@@ -59,6 +59,10 @@ __device__ __forceinline__ void h_piece_a(const HCurA& C, int it, char* slot, in
   _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
   _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
     acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], acc[(IB) * 4 + q_][j_], 0, 0, 0);
+#define H16_MFMAS_Z(XC, WC, IB)                                                                               \
+  _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                          \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                          \
+    acc[(IB) * 4 + q_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WC[j_], XC[q_], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #define H16_SCHED(NRD, VM_MASK)                                                                             \
   _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                       \
     __builtin_amdgcn_sched_group_barrier(W4_SGB_MFMA, 1, 0);                                                \
@@ -135,61 +139,17 @@ __device__ __forceinline__ void h16_body(const GemmArgs& p, char* smem) {
   bool stores_pending = false;
   int c_li = slot;
   while (true) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    f32x4 acc[8][4];          // first touched by the peeled K-tile's MFMAs with C = 0
 
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* xs = smem + a_c;
-      const char* ws = smem + w_c + w_off;
-      // P0
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xb[i] = H16_F(xs, 4 + i, 0);
-      wn_[0] = H16_F(ws, 0, 1);
-      wn_[1] = H16_F(ws, 1, 1);
-      H16_MFMAS(xa, wc, 0)
-      H16_SCHED(6, 0)
-      // P1
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = H16_F(xs, i, 1);
-      wn_[2] = H16_F(ws, 2, 1);
-      wn_[3] = H16_F(ws, 3, 1);
-      h_piece_a(CA, 0, smem + a_2, wave);
-      h_piece_a(CA, 1, smem + a_2, wave);
-      H16_MFMAS(xb, wc, 1)
-      H16_SCHED(6, (1 << 4) | (1 << 10))
-      // P2
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xb[i] = H16_F(xs, 4 + i, 1);
-      h_piece_a(CA, 2, smem + a_2, wave);
-      h_piece_a(CA, 3, smem + a_2, wave);
-      H16_MFMAS(xa, wn_, 0)
-      H16_SCHED(4, (1 << 4) | (1 << 10))
-      advance_a();
-      if (stores_pending) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NST) : "memory");
-        stores_pending = false;
-      } else {
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // P3
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = H16_F(smem + a_1, i, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wc[j] = H16_F(smem + w_1 + w_off, j, 0);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) w4_piece_w<4>(CW, it, ldw, smem + w_c, wave);
-      H16_MFMAS(xb, wn_, 1)
-      H16_SCHED(8, 0xaaaa)                                 // eight W pieces, one after every second MFMA
-      advance_w();
-      { const int t_ = a_c; a_c = a_1; a_1 = a_2; a_2 = t_; }
-      { const int t_ = w_c; w_c = w_1; w_1 = t_; }
+    {
+#define H16_MF_FIRST H16_MFMAS_Z
+#include "gemm_w4h_ktile.inc"
+#undef H16_MF_FIRST
+    }
+    for (int kt = 1; kt < nk; ++kt) {
+#define H16_MF_FIRST H16_MFMAS
+#include "gemm_w4h_ktile.inc"
+#undef H16_MF_FIRST
     }
     const int t = base + c_li;
     int tm_, tn_;

@@ -215,11 +215,15 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float* __restrict__ w
     // ---- pass A: thread n1 = t transforms z[n1 + 16 n2] over n2, twiddles by W256^{n1 k2} ----------
     c32 v[16];
     {
-      const c32* sp = reinterpret_cast<const c32*>(&sm.samp[fl * HOP - SOFF]) + t;   // complex sample n at sp[n - t]
+      // complex sample n of this frame is the c32 at index sbase + n - t of the block's samples; the skipped first 16 complex
+      // samples (window zero) would lie before the array for the block's first frame, so the index - not a pointer - carries
+      // the offset (a pointer before the array is undefined behaviour even when never dereferenced: UBSan on the wavesim build)
+      const c32* sc = reinterpret_cast<const c32*>(sm.samp);
+      const int sbase = (fl * HOP - SOFF) / 2 + t;
       v[0] = (c32){0.f, 0.f};                  // n < 16: real samples < 32, window zero
       v[15] = (c32){0.f, 0.f};                 // n >= 240: real samples >= 480, window zero
 #pragma unroll
-      for (int n2 = 1; n2 < 15; ++n2) v[n2] = sp[16 * n2] * hreg[n2 - 1];
+      for (int n2 = 1; n2 < 15; ++n2) v[n2] = sc[sbase + 16 * n2] * hreg[n2 - 1];
     }
     dft16(v);
     {

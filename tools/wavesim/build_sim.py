@@ -60,7 +60,7 @@ def _newer(out, deps):
 
 
 def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, verbose: bool = True, replace=None, defines=(),
-          tag: str = "", tsan: bool = False) -> str:
+          tag: str = "", tsan: bool = False, ubsan: bool = False) -> str:
     """replace = {"attention.hip": "/path/to/variant.hip"}: a kernel source swapped for an experimental one (tools/experimental),
     defines = ("-DATTN_FAST_PASS", ...): extra compiler flags; both need a `tag` (object files and library are kept apart)."""
     replace = dict(replace or {})
@@ -77,9 +77,11 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
         os.path.join(HERE, "wavesim.h"), os.path.join(INCLUDE, "caco_hip.h"), os.path.abspath(__file__)]
     flags = FLAGS + list(defines) + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
+    if ubsan:          # undefined behaviour in the kernel sources' integer / pointer arithmetic (signed overflow, shifts, misaligned or null access ...)
+        flags = flags + ["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-fno-omit-frame-pointer"]
     if tsan:                                    # kernels instrumented, the runtime (wavesim.cpp) only annotated: see wavesim.cpp
         flags = flags + ["-DWAVESIM_TSAN"]
-    tag = ("." + tag if tag else "") + (".asan" if asan else "") + (".tsan" if tsan else "")
+    tag = ("." + tag if tag else "") + (".asan" if asan else "") + (".tsan" if tsan else "") + (".ubsan" if ubsan else "")
 
     # textually included kernel pieces (csrc/*.inc) get the same translation; the copy in _gen/ is found first by the
     # quote-include of the generated source next to it
@@ -122,7 +124,7 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         objs = list(ex.map(one, srcs))
     if force or not _newer(lib, objs):
         tmp = f"{lib}.{os.getpid()}.tmp"           # link beside it and rename: a process that has the old library mapped keeps it
-        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else []) + (["-fsanitize=thread"] if tsan else [])
+        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else []) + (["-fsanitize=thread"] if tsan else []) + (["-fsanitize=undefined"] if ubsan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -137,5 +139,6 @@ if __name__ == "__main__":
     if "--extra" in sys.argv:
         extra = sys.argv[sys.argv.index("--extra") + 1:]
     tsan = "--tsan" in sys.argv
-    build(force="--force" in sys.argv, asan="--asan" in sys.argv, extra=extra, tsan=tsan,
-          lib=os.path.join(HERE, "libcaco_sim_tsan.so") if tsan else LIB)
+    ubsan = "--ubsan" in sys.argv
+    build(force="--force" in sys.argv, asan="--asan" in sys.argv, extra=extra, tsan=tsan, ubsan=ubsan,
+          lib=os.path.join(HERE, "libcaco_sim_tsan.so") if tsan else (os.path.join(HERE, "libcaco_sim_ubsan.so") if ubsan else LIB))

@@ -78,7 +78,7 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         os.path.join(HERE, "wavesim.h"), os.path.join(INCLUDE, "caco_hip.h"), os.path.abspath(__file__)]
     flags = FLAGS + list(defines) + (["-fsanitize=address", "-fno-omit-frame-pointer"] if asan else [])
     if ubsan:          # undefined behaviour in the kernel sources' integer / pointer arithmetic (signed overflow, shifts, misaligned or null access ...)
-        flags = flags + ["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-fno-omit-frame-pointer"]
+        flags = flags + ["-fsanitize=undefined,float-cast-overflow,float-divide-by-zero", "-fno-sanitize=vptr,function", "-fno-omit-frame-pointer"]
     if tsan:                                    # kernels instrumented, the runtime (wavesim.cpp) only annotated: see wavesim.cpp
         flags = flags + ["-DWAVESIM_TSAN"]
     tag = ("." + tag if tag else "") + (".asan" if asan else "") + (".tsan" if tsan else "") + (".ubsan" if ubsan else "")
@@ -124,7 +124,7 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         objs = list(ex.map(one, srcs))
     if force or not _newer(lib, objs):
         tmp = f"{lib}.{os.getpid()}.tmp"           # link beside it and rename: a process that has the old library mapped keeps it
-        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else []) + (["-fsanitize=thread"] if tsan else []) + (["-fsanitize=undefined"] if ubsan else [])
+        cmd = [CXX, "-shared", "-fPIC", "-o", tmp, *objs, "-lpthread"] + (["-fsanitize=address"] if asan else []) + (["-fsanitize=thread"] if tsan else []) + (["-fsanitize=undefined,float-cast-overflow,float-divide-by-zero"] if ubsan else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

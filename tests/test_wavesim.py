@@ -817,3 +817,48 @@ def test_pingpong_traversal_changes_nothing_but_the_order(sim, tiny_state, caco_
     np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
     np.testing.assert_array_equal(outs["1"][0], outs["0"][0])
     assert np.isfinite(outs["1"][0]).all()
+
+
+def test_argument_validation_returns_status_codes(sim):
+    """Null pointers, zero / negative sizes, unsupported head sizes, null model handles: every entry point answers with a status
+    code and a message (include/caco_hip.h: no exceptions, no crashes across the ABI).  The validation is host code, identical in
+    the product and the simulator build; here a miss would be a segfault of the test process."""
+    import ctypes as C
+    Pn = lambda x: C.c_void_p(x.ctypes.data)
+    a = np.zeros((64, 64), np.uint16); w = np.zeros((128, 64), np.uint16); b = np.zeros(128, np.float32); o = np.zeros((64, 128), np.uint16)
+    xf = np.zeros((4, 128), np.float32); g = np.ones(128, np.float32); of = np.zeros((4, 768), np.float32)
+    qkv = np.zeros((8, 288), np.uint16); ao = np.zeros((8, 96), np.uint16)
+    sm = np.zeros((2, 8), np.float32); idx = np.zeros((2, 3), np.int32); val = np.zeros((2, 3), np.float32)
+    wav = np.zeros((1, 16000), np.float32); pat = np.zeros((1, 16, 256), np.float32)
+    calls = {
+        "gemm null A": lambda: sim.caco_op_gemm_bf16(None, Pn(w), Pn(b), 64, 128, 64, 0, Pn(o), None),
+        "gemm null out": lambda: sim.caco_op_gemm_bf16(Pn(a), Pn(w), Pn(b), 64, 128, 64, 0, None, None),
+        "gemm fp32 null out": lambda: sim.caco_op_gemm_bf16_f32out(Pn(a), Pn(w), Pn(b), None, 64, 128, 64, None, None),
+        "gemm M < 0": lambda: sim.caco_op_gemm_bf16(Pn(a), Pn(w), Pn(b), -5, 128, 64, 0, Pn(o), None),
+        "layernorm null x": lambda: sim.caco_op_layernorm(None, Pn(g), Pn(g), 4, 128, 1e-5, Pn(of), None, None),
+        "layernorm no output": lambda: sim.caco_op_layernorm(Pn(xf), Pn(g), Pn(g), 4, 128, 1e-5, None, None, None),
+        "layernorm 0 rows": lambda: sim.caco_op_layernorm(Pn(xf), Pn(g), Pn(g), 0, 128, 1e-5, Pn(of), None, None),
+        "attention null qkv": lambda: sim.caco_op_attention(None, 288, 96, 192, None, 1, 8, 1, 96, 0, Pn(ao), None),
+        "attention null out": lambda: sim.caco_op_attention(Pn(qkv), 288, 96, 192, None, 1, 8, 1, 96, 0, None, None),
+        "attention seq 0": lambda: sim.caco_op_attention(Pn(qkv), 288, 96, 192, None, 1, 0, 1, 96, 0, Pn(ao), None),
+        "attention head_dim 80": lambda: sim.caco_op_attention(Pn(qkv), 288, 96, 192, None, 1, 8, 1, 80, 0, Pn(ao), None),
+        "similarity null": lambda: sim.caco_similarity(None, 2, None, 2, 768, 1.0, None, 2, None),
+        "l2_normalize null": lambda: sim.caco_l2_normalize(None, 2, 768, None, None),
+        "topk null": lambda: sim.caco_topk(None, 2, 8, 8, 1, 3, None, None, None),
+        "topk k = 0": lambda: sim.caco_topk(Pn(sm), 2, 8, 8, 1, 0, Pn(idx), Pn(val), None),
+        "mel null": lambda: sim.caco_mel_patches(None, 1, 16000, 16, 0.2, 0.9, None, 1, None, None, None, None),
+        "mel batch 0": lambda: sim.caco_mel_patches(Pn(wav), 0, 16000, 16, 0.2, 0.9, Pn(pat), 0, None, None, None, None),
+        "mel samples < 0": lambda: sim.caco_mel_patches(Pn(wav), 1, -3, 16, 0.2, 0.9, Pn(pat), 0, None, None, None, None),
+        "token_group_mean null": lambda: sim.caco_token_group_mean(None, 1, 16, 128, 8, None, None),
+        "audio forward, null model": lambda: sim.caco_audio_forward(None, Pn(pat), 0, None, None, None, 1, 16, 1, Pn(of), None, None),
+        "text forward, null model": lambda: sim.caco_text_forward(None, None, None, None, 1, 4, 1, None, None, None),
+        "encode_audio, null model": lambda: sim.caco_encode_audio(None, Pn(wav), 1, 16000, 16, Pn(of), None),
+        "load_tensor, null model": lambda: sim.caco_load_tensor(None, b"x", Pn(xf), None, 0),
+        "decode_step null": lambda: sim.caco_decode_step(None, None, None, None),
+    }
+    for name, call in calls.items():
+        assert call() != 0, f"{name}: accepted"
+        assert len(sim.caco_last_error()) > 0, name
+    sim.caco_destroy(None)             # no-ops on null handles
+    sim.caco_decode_end(None)
+    assert sim.caco_profile_report(None, 0) >= 0

@@ -276,6 +276,16 @@ SWITCH_NAMES = ("CACO_PINGPONG", "CACO_POS_FUSE", "CACO_POOL_FUSE", "CACO_ATTN_S
                 "CACO_W8_MIN_TILES", "CACO_W4H_MAX_TILES")
 
 
+def _lib_path():
+    from cacophony_amd import _lib
+    return _lib.LIB_PATH
+
+
+def _lib_is_product():
+    from cacophony_amd import _lib
+    return os.path.realpath(_lib.LIB_PATH) == os.path.realpath(_lib.PRODUCT_LIB_PATH)
+
+
 def _switches_in_force(lib):
     """What the library itself reports (caco_get_switch), plus the LayerNorm-fold default: an A/B line says what it measured."""
     if lib is None:
@@ -339,7 +349,7 @@ def main():
         from cacophony_amd.dist import gather_packed
         from cacophony_amd.model import create_caco_model, similarity
 
-        lib = _lib.load()
+        lib = _lib.load()          # refuses any library but cacophony_amd/libcaco_hip.so unless CACO_ALLOW_VARIANT_LIB=1
         state = synth.make_caco_state(Cfg.default_audio_config(), Cfg.default_text_config(), Cfg.default_caco_config())
         model = create_caco_model(device=device).load_state_dict(state)
         wav, ids, mask = _make_inputs(B_PER_GPU, rank, device)
@@ -393,15 +403,14 @@ def main():
                 stages[name] = ent
             dom = stages.get("audio.gemm_fc1")
             # HBM bytes of one fc1 launch: a committed TCC-counter measurement (tools/pmc_hbm.sh), quoted ONLY when it was taken
-            # with the tile order this run uses (its "w_ngroup" field; files without the field predate the n-tile groups and
-            # describe one group).  Anything else would pair this run's time with another schedule's bytes.
+            # with the tile order this run uses (its "w_ngroup" field; a file without the field is of unknown order and never quoted).  Anything else would pair this run's time with another schedule's bytes.
             traffic, traffic_source = None, None
             try:
                 import glob
                 ngroup_now = int(lib.caco_get_switch(b"CACO_W_NGROUP"))
                 for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True):
                     rec = json.load(open(cand))
-                    if int(rec.get("w_ngroup", 0)) == ngroup_now:
+                    if "w_ngroup" in rec and int(rec["w_ngroup"]) == ngroup_now:      # no field = tile order unknown: never quoted
                         traffic = int(rec["hbm_bytes"])
                         traffic_source = (os.path.relpath(cand, REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 "
                                           "launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
@@ -472,6 +481,10 @@ def main():
                                    "(one RCCL all-gather of the packed [256,2,768] fp32 banks, local [256, N*256] row block)",
                        "global_batch": world * B_PER_GPU, "clip": "10 s @ 16 kHz (160000 samples, 500 patches, 496 valid)",
                        "caption_tokens": TEXT_LEN, "parallelism": f"dp{world}", "weights": "seeded random init (no checkpoint offline)",
+                       # which library was timed: a headline line and an A/B line of a variant build are told apart after the fact
+                       "lib_path": os.path.relpath(os.path.realpath(_lib_path()), REPO) if lib is not None else None,
+                       "lib_is_product": _lib_is_product() if lib is not None else None,
+                       "caco_version": lib.caco_version().decode() if lib is not None else None,
                        "gemm_tile": int(lib.caco_set_gemm_tile(0)) if lib is not None else None,
                        # run-time switches in force: an A/B line says what it measured
                        "switches": _switches_in_force(lib)},

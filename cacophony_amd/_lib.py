@@ -12,7 +12,10 @@ import re
 from typing import List, Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CACO_LIB_PATH") or os.path.join(HERE, "libcaco_hip.so")
+PRODUCT_LIB_PATH = os.path.join(HERE, "libcaco_hip.so")
+# CACO_LIB_PATH (another build of the library: an A/B variant, the simulator build of the test suite) is honoured ONLY together with
+# CACO_ALLOW_VARIANT_LIB=1 - load() refuses it otherwise, so that nothing can stand in for the product by accident.
+LIB_PATH = os.environ.get("CACO_LIB_PATH") or PRODUCT_LIB_PATH
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "caco_hip.h")
 
 CACO_OK = 0
@@ -98,6 +101,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if os.path.realpath(LIB_PATH) != os.path.realpath(PRODUCT_LIB_PATH) and os.environ.get("CACO_ALLOW_VARIANT_LIB") != "1":
+        raise RuntimeError(
+            f"CACO_LIB_PATH={LIB_PATH} is not the product library {PRODUCT_LIB_PATH}: set CACO_ALLOW_VARIANT_LIB=1 to run an A/B "
+            "variant or the simulator build on purpose")
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (build it with `python -m cacophony_amd.build`); "

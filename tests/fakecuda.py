@@ -125,6 +125,7 @@ def install():
     import build_sim
     path = build_sim.build(verbose=False)                     # rebuilds tools/wavesim/libcaco_sim.so if it is stale
     os.environ["CACO_LIB_PATH"] = path
+    os.environ["CACO_ALLOW_VARIANT_LIB"] = "1"          # _lib.load() refuses any library but the product's without it
     if "cacophony_amd._lib" in sys.modules:
         sys.modules["cacophony_amd._lib"].LIB_PATH = path
     c = torch.cuda

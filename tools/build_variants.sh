@@ -4,11 +4,12 @@
 set -e
 cd "$(dirname "$0")/.."
 rm -f cacophony_amd/_variants/*.so cacophony_amd/_variants/*.o
-# the parked max-free attention pass: the experimental file replaces attention.hip for this one build
-cp cacophony_amd/csrc/attention.hip /tmp/_attention_saved.hip
-tail -n +10 tools/experimental/attention_fastpass.hip > cacophony_amd/csrc/attention.hip
-bash tools/build_variant.sh fastpass attention.hip -DATTN_FAST_PASS || true
-cp /tmp/_attention_saved.hip cacophony_amd/csrc/attention.hip
+# the parked max-free attention pass: the experimental file is compiled IN PLACE OF attention.hip from a temp copy (the product
+# source is never written: an interrupted run cannot leave csrc/attention.hip replaced)
+TMPSRC=$(mktemp -d)/attention_fastpass.hip
+tail -n +10 tools/experimental/attention_fastpass.hip > "$TMPSRC"
+SRC_OVERRIDE="$TMPSRC" bash tools/build_variant.sh fastpass attention.hip -DATTN_FAST_PASS || true
+rm -rf "$(dirname "$TMPSRC")"
 # round 4: K fragment reads of the score phase pinned 1 / 2 steps ahead of their MFMAs (the default build's ISA waits lgkmcnt(0) after
 # every read there: one fragment buffer at 256 VGPRs); same registers, same results (simulator)
 bash tools/build_variant.sh kpipe1 attention.hip -DATTN_KPIPE=1

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Energy per launch at a FIXED shader clock (rocm-smi performance-determinism mode, below the throttle point), so that the
 # socket power of two kernels doing the same work in the same time compares directly.   bash tools/energy_ab.sh [MHz] [shapes]
+export CACO_ALLOW_VARIANT_LIB=1      # cacophony_amd/_lib.py refuses CACO_LIB_PATH without it
 MHZ=${1:-1500}; SHAPES=${2:-fc1}
 rocm-smi --setperfdeterminism $MHZ 2>&1 | grep -v "^$" | tail -3
 for v in "" _variants/libcaco_hip_mf16.so _variants/libcaco_hip_mf16_noepi.so _variants/libcaco_hip_mf16_nodma.so _variants/libcaco_hip_mf16_noreads.so; do

@@ -10,7 +10,7 @@
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}
-OUT=${OUT:-gpurun_out/r4_v0}
+OUT=${OUT:-gpurun_out/r5_v0}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
@@ -24,14 +24,14 @@ tail -3 "$OUT/pytest_gpu_experimental.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
-bash tools/profile_bench.sh r4_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
-cp gpurun_out/prof_r4_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+bash tools/profile_bench.sh r5_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
+cp gpurun_out/prof_r5_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 fi
 if want ab; then
 # every run-time switch against the default, interleaved inside ONE process (caco_set_switch), with the flip / delete verdict
 (timeout 900 python tools/ab_switches.py --reps 5 --steps 10 --out "$OUT/ab_switches.json" 2>&1 | tail -40) | tee "$OUT/ab_switches.txt"
-CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r4_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
-cp gpurun_out/prof_r4_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
+CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r5_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
+cp gpurun_out/prof_r5_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
   for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"

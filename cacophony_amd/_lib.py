@@ -113,8 +113,17 @@ def load() -> C.CDLL:
     # copy by SONAME; loading /opt/rocm's copy first leaves the process with two runtimes and no visible device.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    product = os.path.realpath(LIB_PATH) == os.path.realpath(PRODUCT_LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        try:
+            fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
+        except AttributeError:
+            # an older build of the library as an A/B arm (tools/build_r2_arm.sh: commit cccbeef predates the switch API): the
+            # missing entry point answers "unknown switch" / CACO_ERR_INVALID.  Never for the product library.
+            if product or name not in ("caco_set_switch", "caco_get_switch"):
+                raise
+            setattr(lib, name, (lambda *a: CACO_ERR_INVALID) if name == "caco_set_switch" else (lambda *a: -2 ** 31))
+            continue
         fn.restype = res
         fn.argtypes = args
     # caco_default_config memsets sizeof(caco_config) bytes: a stale struct on either side would overflow

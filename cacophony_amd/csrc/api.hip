@@ -766,6 +766,17 @@ int caco_set_switch(const char* name, int32_t value) {
   CACO_REQUIRE(name, "caco_set_switch: null name");
   for (int i = 0; i < SW_COUNT; ++i)
     if (!strcmp(name, g_switches[i].name)) {
+      // per-switch ranges: INT32_MIN is the "environment not read yet" sentinel and must never be stored (it would re-arm the
+      // getenv), and an out-of-range value would go straight to a launch path
+      bool ok = value != INT32_MIN;
+      switch ((Switch)i) {
+        case SW_PINGPONG: case SW_POS_FUSE: case SW_POOL_FUSE: case SW_ATTN_SMALL: ok = ok && (value == 0 || value == 1); break;
+        case SW_ATTN_ROWS: ok = ok && (value == 32 || value == 64); break;
+        case SW_W_NGROUP: ok = ok && value >= -1 && value <= 4096; break;
+        case SW_W8_MIN_TILES: case SW_W4H_MAX_TILES: ok = ok && value >= 0; break;
+        default: break;
+      }
+      CACO_REQUIRE(ok, "caco_set_switch: value %d out of range for %s", (int)value, name);
       sw((Switch)i);                               // settle the environment's initial value first, so that it cannot overwrite this one
       g_switches[i].value.store(value, std::memory_order_relaxed);
       return CACO_OK;

@@ -96,7 +96,11 @@ __device__ __forceinline__ float erf_rational_f(float z) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
   const float h = 0.5f * x;
+#ifdef CACO_LIBM_ERF   // bisection arm `libm_erf` (tools/build_variants.sh): rounds 1-2's form on the device library's erff
+  return __builtin_fmaf(h, erff(x * 0.70710678118654752440f), h);
+#else
   return __builtin_fmaf(h, erf_rational_f(x * 0.70710678118654752440f), h);
+#endif
 }
 
 // host: fp32 -> bf16 round-to-nearest-even

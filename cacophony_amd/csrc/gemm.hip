@@ -214,14 +214,20 @@ int launch_epi(const GemmArgs& p, hipStream_t st, int epi, int act) {
 
 }  // namespace
 
-// the dispatch rule of launch_epi for callers that only take a w8-specific form when w8 would run anyway
+// the dispatch rule of launch_epi (same order of tests) for callers that only take a w8-specific form when w8 would run the
+// plain form anyway.  A forced 4-wave kernel (4256 / 4128) that does not carry the shape / epilogue falls through to the
+// default choice there, and so does this function.
 bool gemm_bf16_picks_w8(const GemmArgs& p, int epi) {
   const int cfg = gemm_tile_config();
   if (!gemm_bf16_w8_ok(p, epi) || p.K % BK != 0 || p.N % 128 != 0) return false;
   if (cfg == 8256) return true;
-  if (cfg != 256) return false;
-  const int w8_min = sw(SW_W8_MIN_TILES);
-  return ((p.M + 255) / 256) * (int64_t)(p.N / 128) >= w8_min;
+  if (cfg == 128 || cfg == 2256) return false;
+  const bool w4_ok = p.bias && ((epi == EPI_BF16 && !p.resid) || epi == EPI_F32);
+  if ((cfg == 4256 || cfg == 4128) && w4_ok) return false;          // the forced 4-wave kernel carries it
+  const int64_t tiles_x = ((p.M + 255) / 256) * (int64_t)(p.N / 128);
+  const int w8_min = sw(SW_W8_MIN_TILES), w4h_max = sw(SW_W4H_MAX_TILES);
+  if (w4h_max > 0 && w4_ok && tiles_x >= w8_min && ((p.M + 255) / 256) * (int64_t)(p.N / 256) < w4h_max) return false;
+  return tiles_x >= w8_min;
 }
 
 static int g_tile_cfg = -1;

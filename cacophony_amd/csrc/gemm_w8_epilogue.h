@@ -33,13 +33,21 @@ __device__ __forceinline__ float w4_epi_act(float x) {
 // the scalar offset; under the LLVM model that leaves the rows of a ragged last M tile unprotected (the wavesim build, whose
 // descriptor follows that model, corrupts the heap at M % 256 != 0 with the old form) - whether the hardware of rounds 1-2
 // really wrote past row M is NOT established (tests/test_gpu_ops.py::test_gemm_ragged_m_writes_nothing_past_row_m is the
-// hardware check; tools/build_variant.sh can rebuild the old form for it).  Only the column half j * 128, which is always
-// inside a valid row's 256-byte span, still rides in the scalar offset.
+// hardware check).  -DW8_R2_ADDR (bisection arm `r2addr`, tools/build_variants.sh) puts the row-block part back into the
+// scalar offset - rounds 1-2's addressing and nothing else - so that one GPU run of that test on that arm settles the
+// question; tools/build_r2_arm.sh builds the whole round-2 library (commit cccbeef) as the arm that changes everything at
+// once.  Only the column half j * 128, which is always inside a valid row's 256-byte span, still rides in the scalar offset.
+// W8_VS(v, rows, col) expands to the (per-lane offset, scalar offset) argument pair of a buffer access.
 // (Measured dead end: storing the accumulator layout directly - 8-byte pieces, no LDS transposition, no barrier after
 // the epilogue - is 30-40 % SLOWER on the QKV / fc1 shapes: partial-line writes from 32 rows per instruction.)
 // Cache-policy bits of the epilogue's stores / residual loads: 2 = nt (streaming).  The outputs are far larger than the
 // L2 and are not re-read by this kernel; marking them streaming keeps the weight / activation tiles of the K-loop
 // resident instead: QKV -5 %, fc1 -4.6 %, out-proj -5.8 % (nt residual loads), fc2 +-0; sc0 / sc1 variants equal.
+#ifdef W8_R2_ADDR
+#define W8_VS(v, rows, col) (v), (rows) + (col)
+#else
+#define W8_VS(v, rows, col) (v) + (rows), (col)
+#endif
 #ifndef W8_ST_AUX
 #define W8_ST_AUX 2
 #endif
@@ -165,7 +173,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
       for (int tt = 0; tt < 4; ++tt) {
         const int row = tt * 8 + rrow;
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, voff + (i * 32 + tt * 8) * rowb, 0, W8_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_r, W8_VS(voff, (i * 32 + tt * 8) * rowb, 0), W8_ST_AUX);
       }
       CACO_WAVE_LDS_SYNC();
     }
@@ -241,7 +249,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         if constexpr (MODE == 5) dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, gidx[i][tt] * rowb + c8 * 16, j * 128, 0);   // table rows are re-used: default cache policy
-        else dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, voff + (i * 32 + tt * 8) * rowb, j * 128, W8_LD_AUX);
+        else dst[tt] = __builtin_amdgcn_raw_buffer_load_b128(res_r, W8_VS(voff, (i * 32 + tt * 8) * rowb, j * 128), W8_LD_AUX);
       }
     };
     if (has_resid) {
@@ -268,13 +276,17 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
         const int row = tt * 8 + rrow;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
         if (has_resid) v += __builtin_bit_cast(f32x4, res[s % RN][tt]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, voff + (i * 32 + tt * 8) * rowb, j * 128, W8_ST_AUX_F32);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_r, W8_VS(voff, (i * 32 + tt * 8) * rowb, j * 128), W8_ST_AUX_F32);
         if (produce_xb) {
           bf16x4 b;
 #pragma unroll
           for (int r = 0; r < 4; ++r) b[r] = (bf16_t)v[r];
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          #ifdef W8_R2_ADDR
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, voff >> 1, ((i * 32 + tt * 8) * rowb + j * 128) >> 1, 0);
+#else
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), xb_r, (voff + (i * 32 + tt * 8) * rowb) >> 1, (j * 128) >> 1, 0);
+#endif
         }
         if (produce_st) {
           const float a1 = (v[0] + v[1]) + (v[2] + v[3]);

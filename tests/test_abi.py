@@ -119,6 +119,12 @@ def test_run_time_switches_read_their_environment_once_then_only_the_api(tmp_pat
     with _lib.switch("CACO_POS_FUSE", 1 - prev):
         assert lib.caco_get_switch(b"CACO_POS_FUSE") == 1 - prev
     assert lib.caco_get_switch(b"CACO_POS_FUSE") == prev
+    # values are validated per switch; the "environment not read yet" sentinel can never be stored (it would re-arm getenv)
+    for name, bad in ((b"CACO_POS_FUSE", -2 ** 31), (b"CACO_W_NGROUP", -2 ** 31), (b"CACO_W_NGROUP", -2), (b"CACO_ATTN_ROWS", 48),
+                      (b"CACO_W8_MIN_TILES", -1), (b"CACO_PINGPONG", 2)):
+        before = lib.caco_get_switch(name)
+        assert lib.caco_set_switch(name, bad) == _lib.CACO_ERR_INVALID and b"out of range" in lib.caco_last_error(), (name, bad)
+        assert lib.caco_get_switch(name) == before
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
         "import os, sys; sys.path.insert(0, %r)\n"

@@ -38,6 +38,12 @@ bash tools/build_variant.sh bf16_wb gemm_w8.hip -DW8_ST_AUX=0          # the bf1
 bash tools/build_variant.sh f32_wb gemm_w8.hip -DW8_ST_AUX_F32=0
 bash tools/build_variant.sh f32_wb_ld0 gemm_w8.hip -DW8_ST_AUX_F32=0 -DW8_LD_AUX=0
 bash tools/build_variant.sh classic gemm_w8.hip -DW8_CLASSIC
+# round 5: single-change bisection arms for the items `classic` does not isolate - the erf-GELU on the device
+# library's erff as in rounds 1-2 (every GEMM translation unit), and rounds 1-2's epilogue addressing (row block in the scalar offset)
+bash tools/build_variant.sh libm_erf gemm.hip,gemm_x.hip,gemm_w8.hip,gemm_w4q.hip,gemm_w4h.hip -DCACO_LIBM_ERF
+bash tools/build_variant.sh r2addr gemm_w8.hip -DW8_R2_ADDR
+# ... and the arm that changes everything at once: the whole library of commit cccbeef, the last binary an MI355X has run
+bash tools/build_r2_arm.sh
 bash tools/build_variant.sh classic_f32direct gemm_w8.hip -DW8_CLASSIC -DW8_F32_DIRECT=12
 python -m cacophony_amd.build --force >/dev/null
 # every variant must resolve all its symbols (a kernel-side signature change breaks the parked attention variant silently otherwise)

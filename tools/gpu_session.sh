@@ -1,7 +1,7 @@
 #!/bin/bash
 # The first GPU call once the pool reopens (round 3 wrote everything below without one):
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
-#   bash tools/gpu_session.sh all                                    everything in one call (~60 min)
+#   bash tools/gpu_session.sh all                                    everything in one call (~60 min); `bisect` is never part of `all`
 # 1. truth: hardware record of the DEFAULT build: pytest -m gpu (default path), the experimental cases apart, smoke, bench,
 #    rocprofv3 kernel stats  -> gpurun_out/r4_v0/   (copy to profiles/r4_v0/)
 # 2. ab: every run-time switch against the default, interleaved in one process (tools/ab_switches.py: flip / delete verdicts),
@@ -35,6 +35,19 @@ cp gpurun_out/prof_r5_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switc
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
   for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
+fi
+# bisection arms (round 5): only worth running when `truth` shows a red GEMM / model case, or to settle whether
+# rounds 1-2's epilogue addressing wrote past row M on hardware (r2 and r2addr under test_gemm_ragged_m_writes_nothing_past_row_m).
+#   r2 = the whole library of commit cccbeef (last binary an MI355X ran), classic = r4's peeled K-tile + packed bias epilogue reverted,
+#   libm_erf = r4's rational erf reverted, r2addr = r3's per-lane row offsets reverted.  (tools/build_variants.sh builds all four.)
+if [ "$PART" = bisect ]; then
+  for v in r2 classic libm_erf r2addr; do
+    L=$PWD/cacophony_amd/_variants/libcaco_hip_$v.so
+    [ -f "$L" ] || { echo "$v: not built"; continue; }
+    (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$L timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "gemm or ragged" 2>&1 | tail -15) > "$OUT/pytest_arm_$v.txt"
+    echo "== arm $v"; tail -3 "$OUT/pytest_arm_$v.txt"
+  done
+  (timeout 900 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_arms.json" default r2 classic libm_erf r2addr 2>&1 | tail -30) | tee "$OUT/ab_arms.txt"
 fi
 # compile-time variants prepared by tools/build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
 if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then

@@ -237,6 +237,10 @@ int launch_w8(const GemmArgs& p, hipStream_t st) {
   return check_hip(hipGetLastError(), "gemm_bf16_w8 launch");
 }
 
+#ifdef W8_F32_SKEW      // variant build `skew` only (tools/build_variants.sh): the fp32 + residual epilogue under the K-loop
+#include "gemm_w8_skew.inc"
+#endif
+
 }  // namespace
 
 bool gemm_bf16_w8_ok(const GemmArgs& p, int epi) {
@@ -262,6 +266,13 @@ int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
     return launch_w8<EPI_F32, ACT_NONE, 5>(p, st);
   }
   if (plain && epi == EPI_F32 && act == ACT_NONE) {
+#ifdef W8_F32_SKEW
+    if (p.resid) {
+      int num_cu = 0;
+      CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(&gemm_bf16_w8s_kernel), W_SMEM, &num_cu));
+      if (gemm_bf16_w8s_ok(p, num_cu / 8 * 8)) return launch_w8s(p, st);
+    }
+#endif
     if (p.resid) return launch_w8<EPI_F32, ACT_NONE, 2>(p, st);
     return launch_w8<EPI_F32, ACT_NONE, 1>(p, st);
   }

@@ -72,6 +72,90 @@ def test_gemm_f32_residual_in_place_and_plain(sim, tile):
     sim.caco_set_gemm_tile(256)
 
 
+def _variant_sim(tag, defines):
+    """A variant build of the simulator library (its own object files and .so, tools/wavesim/libcaco_sim_<tag>.so), bound like
+    simlib.load() but NOT cached as the suite's library."""
+    import ctypes as Ct
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "wavesim"))
+    import build_sim
+    from cacophony_amd import _lib
+    lib = Ct.CDLL(build_sim.build(defines=tuple(defines), tag=tag, verbose=False))
+    for name, (res, args) in _lib._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+@pytest.fixture(scope="module")
+def skew_sim():
+    return _variant_sim("skew", ["-DW8_F32_SKEW"])
+
+
+def _skew_case(lib, M, N, K, seed, inplace=True, guard=3):
+    a = _rand((M, K), seed).bfloat16()
+    w = _rand((N, K), seed + 1, 1.0 / math.sqrt(K)).bfloat16()
+    bias, x = _rand((N,), seed + 2), _rand((M, N), seed + 3)
+    ref = a.float() @ w.float().T + bias + x                       # torch fp32, the bar of the GPU op tests
+    ref64 = a.double() @ w.double().T + bias.double() + x.double()
+    buf = torch.full((M + 2 * guard, N), 777.0)
+    buf[guard:guard + M] = x if inplace else 0.0
+    out = buf[guard:guard + M]
+    lib.caco_set_gemm_tile(8256)
+    try:
+        rc = lib.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(out) if inplace else P(x), M, N, K, P(out), None)
+        assert rc == 0, lib.caco_last_error()
+    finally:
+        lib.caco_set_gemm_tile(256)
+    assert bool((buf[:guard] == 777.0).all()) and bool((buf[guard + M:] == 777.0).all()), "rows outside [0, M) were written"
+    return out, ref, ref64
+
+
+@pytest.mark.parametrize("M,N,K,inplace", [
+    (2048, 768, 768, True),        # out-proj shape at 8 panels: D = 1, 5 teams of 3 workgroups on the simulator's 16 CUs
+    (2000, 768, 768, True),        # ragged last panel: rows >= M read as zeros and are dropped by the descriptors
+    (1800, 768, 640, False),       # nk = 10, separate residual; teams with 1 and 2 panels
+    (4100, 768, 1024, True),       # nk = 16: D = 2; 17 panels over 5 teams (periods 3 and 4), ragged
+    (2304, 512, 3072, True),       # fc2 K: nk = 48, D = 6; two n-tiles: 8 teams, 9 panels (one team walks two)
+    (2304, 1024, 576, True),       # the smallest K the kernel takes (nk = 9); four n-tiles: 4 teams
+])
+def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
+    """Variant build `skew` (-DW8_F32_SKEW, csrc/gemm_w8_skew.inc): the fp32 + bias + residual GEMM whose epilogue runs under its
+    own K-loop.  Against torch fp32 at fp32 rounding (sum order differs from the other kernels: bias first, K-tiles rotated per
+    row block), with guard rows around the output, in place and with a separate residual; and the DEFAULT build on the same
+    case must differ from it in bits (otherwise the launch fell back to gemm_bf16_w8 and the case tests nothing)."""
+    out, ref, ref64 = _skew_case(skew_sim, M, N, K, 40)
+    err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
+    err32 = ((ref.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
+    # measured against float64, as a fraction of 1 + |ref|: 1.8e-6 .. 2.4e-6 for K <= 1024 and 5.9e-6 at K = 3072; gemm_bf16_w8 on
+    # the same cases 1.8e-6 resp. 4.8e-6 (fp32 accumulation of K products either way; the K-tiles are summed in a rotated order
+    # here), torch's own fp32 product 1.1e-6
+    assert err <= (3e-6 if K <= 1024 else 7e-6), f"max error {err:.3e} relative to 1 + |ref| (torch fp32 itself: {err32:.3e})"
+    d32 = ((out - ref).abs() / (ref.abs() + 1.0)).max().item()      # two fp32 roundings apart: up to the sum of both errors
+    print(f"[skew] M {M} N {N} K {K}: vs float64 {err:.2e} (torch fp32 {err32:.2e}), vs torch fp32 {d32:.2e}")
+    assert d32 <= (3.5e-6 if K <= 1024 else 7e-6)
+    base, _, _ = _skew_case(sim, M, N, K, 40)
+    assert not torch.equal(base, out), "identical bits: the skewed kernel did not run"
+    assert (base - out).abs().max().item() < 1e-4
+
+
+def test_gemm_skewed_falls_back_where_it_does_not_apply(skew_sim, sim):
+    """Launches that do not fill the chip, K < 576 and gathered / absent residuals stay on gemm_bf16_w8: bitwise the default's."""
+    for M, N, K in ((1024, 768, 768), (2048, 768, 512), (2048, 256, 768)):
+        a, _, _ = _skew_case(skew_sim, M, N, K, 50)
+        b, _, _ = _skew_case(sim, M, N, K, 50)
+        assert torch.equal(a, b), (M, N, K)
+
+
+def test_gemm_skewed_weak_wait_is_caught():
+    """The skewed kernel waits for its residual registers itself (inline-assembly loads the compiler's wait-count pass does not
+    see).  On the simulator such a load lands in its destination variable at the covering wait; a build whose wait leaves ONE
+    more operation in flight (13 instead of 12) must produce stale sums - i.e. the model does check that count."""
+    weak = _variant_sim("skew_weakwait", ["-DW8_F32_SKEW", "-DW8S_SIM_RD_WAIT=13"])
+    out, ref, _ = _skew_case(weak, 2048, 768, 768, 40)
+    assert (out - ref).abs().max().item() > 1e-2
+
+
 def test_gemm_every_tile_kernel_gives_the_same_bits(sim):
     """What makes a clip's embedding independent of its batch mates (tests/test_gpu_model.py::test_odd_batch_sizes_...):
     the kernel families a batch size selects - 128 x 128, x, w8, w4q, w4h - accumulate K in the same order and round the

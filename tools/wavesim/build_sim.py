@@ -9,6 +9,7 @@ Source translation (the only edits made to a kernel source; everything else is t
   * `asm volatile("s_waitcnt vmcnt(%0) ..." :: "n"(E) ...)` -> wavesim::s_waitcnt_n("...", E)
   * `extern __shared__ ... T NAME[];`                       -> T* NAME = (T*)wavesim::dyn_lds();
   * `__attribute__((amdgpu_...(...)))` on kernels           -> dropped (occupancy hints)
+  * any other inline assembly must sit in the #else branch of an `#ifdef WAVESIM` and carry the marker `/* hw-only */`
 Textually included kernel pieces (`csrc/*.inc`, e.g. the K-tile body of gemm_w8) get the same translation; the translated copy is
 written next to the generated source, where the quote-include finds it first.
 """
@@ -49,7 +50,8 @@ def translate(text: str) -> str:
     text = _ASM.sub(asm, text)
     text = re.sub(r"__attribute__\(\(amdgpu_[a-z_]+\([^)]*\)\)\)", "", text)      # kernel-only attributes
     text = _EXT.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(wavesim::dyn_lds());", text)
-    left = [l for l in text.splitlines() if re.search(r"\basm\s+volatile", l) and '""' not in l]
+    # a line marked /* hw-only */ sits in the #else branch of an #ifdef WAVESIM (the simulator compiles the other branch)
+    left = [l for l in text.splitlines() if re.search(r"\basm\s+volatile", l) and '""' not in l and "/* hw-only */" not in l]
     if left:
         raise ValueError("untranslated inline asm:\n" + "\n".join(left))
     return text

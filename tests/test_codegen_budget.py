@@ -21,9 +21,9 @@ FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast --
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 
 
-def _assembly(src, tmp_path_factory):
+def _assembly(src, tmp_path_factory, defines=()):
     out = os.path.join(str(tmp_path_factory.mktemp("isa")), src.replace(".hip", ".s"))
-    r = subprocess.run([HIPCC, *FLAGS, "-I", os.path.join(REPO, "include"), os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
+    r = subprocess.run([HIPCC, *FLAGS, *defines, "-I", os.path.join(REPO, "include"), os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return open(out).read()
 
@@ -107,6 +107,108 @@ def test_persistent_gemm_resources_and_overhead(w8_asm):
     f32 = _find(kernels, "gemm_bf16_w8_kernelILi1ELi0ELi2E")
     ops = Counter(i.split()[0] for i in store(f32))
     assert ops["buffer_store_dwordx4"] == 32 and ops["buffer_load_dwordx4"] >= 32
+
+
+def _vregs(operand):
+    """'v[12:15]' / 'v7' -> set of VGPR numbers (anything else: empty)."""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", operand)
+    return {int(m.group(1))} if m else set()
+
+
+def test_skewed_row_block_variant_budget(tmp_path_factory):
+    """Variant build `skew` (-DW8_F32_SKEW, csrc/gemm_w8_skew.inc: the fp32 + residual epilogue under the K-loop; never part of the
+    product library).  Resources the design depends on, the counted waits, and the one thing inline-assembly loads put at risk:
+    the residual registers are written by a load the compiler does not track and become valid only at the kernel's own
+    s_waitcnt vmcnt(12) of the NEXT event - nothing may read, copy or spill them in between."""
+    text = _assembly("gemm_w8.hip", tmp_path_factory, ["-DW8_F32_SKEW"])
+    kernels, meta = _kernels(text)
+    name = _find(meta, "gemm_bf16_w8s_kernel")
+    assert meta[name]["scratch"] == 0 and meta[name]["vgpr"] <= 256 and meta[name]["occ"] == 2, meta[name]
+    # the other kernels of the translation unit are the default build's (the variant only adds one)
+    assert all(m["scratch"] == 0 for k, m in meta.items() if "gemm_bf16_w8_kernel" in k)
+    blocks = kernels[name]
+    flat = [i for b in blocks for i in b]
+    ops = Counter(i.split()[0] for i in flat)
+    assert ops["v_mfma_f32_16x16x32_bf16"] % 64 == 0 and ops["v_mfma_f32_16x16x32_bf16"] <= 1024, ops["v_mfma_f32_16x16x32_bf16"]
+    assert not any(o.startswith("scratch_") for o in ops)
+    # eight event sites: 4 residual loads (inline assembly: "offen offset:<n> nt") + 4 direct fp32 stores each
+    rd_loads = [i for i in flat if i.startswith("buffer_load_dwordx4") and " nt" in i and "lds" not in i]
+    stores = [i for i in flat if i.startswith("buffer_store_dwordx4")]
+    assert len(rd_loads) == 32 and len(stores) == 32, (len(rd_loads), len(stores))
+    # waits: vmcnt(0) only before the loop and at the very end; the events' and the K-tile barriers' counted waits are 12 / 4
+    waits = Counter(re.search(r"vmcnt\((\d+)\)", i).group(1) for i in flat if i.startswith("s_waitcnt") and "vmcnt" in i)
+    assert waits["12"] >= 16 and waits["4"] >= 8, waits
+    loop_blocks = [b for b in blocks if any("v_mfma" in i for i in b)]
+    assert not any("vmcnt(0)" in i for b in loop_blocks for i in b), "a full drain inside the K-loop"
+    # the residual registers: the same 16 at every event site ...
+    rd_regs = set()
+    for i in rd_loads:
+        rd_regs |= _vregs(i.split()[1].rstrip(","))
+    assert len(rd_regs) == 16, sorted(rd_regs)
+    # ... and on EVERY path between a residual load and the event wait that makes it valid (the plain `s_waitcnt vmcnt(12)`; the
+    # K-tile barrier's wait carries lgkmcnt(0) as well and leaves the event's loads in flight) no instruction may name one of the
+    # registers in flight.  Forward data flow over the kernel's control-flow graph (labels, branches, fall-through).
+    def names(instr):
+        regs = set()
+        for tok in re.findall(r"v\[\d+:\d+\]|v\d+", instr):
+            regs |= _vregs(tok)
+        return regs
+
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+    end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))
+    labels, body, cur = ["entry"], {"entry": []}, "entry"
+    for l in lines[start + 1:end]:
+        l = l.split(";")[0].strip()
+        if not l:
+            continue
+        m = re.match(r"(\.LBB\d+_\d+):", l)
+        if m:
+            cur = m.group(1)
+            labels.append(cur)
+            body[cur] = []
+        elif not l.startswith("."):
+            body[cur].append(l)
+    succ = {}
+    for n, lab in enumerate(labels):
+        out = [i.split()[-1] for i in body[lab] if i.startswith(("s_cbranch", "s_branch"))]
+        last = body[lab][-1] if body[lab] else ""
+        if not last.startswith(("s_branch", "s_endpgm")) and n + 1 < len(labels):
+            out.append(labels[n + 1])
+        succ[lab] = out
+
+    def transfer(lab, state, check):
+        state = set(state)
+        for i in body[lab]:
+            if i.startswith("s_waitcnt") and ("vmcnt(0)" in i or ("vmcnt(12)" in i and "lgkmcnt" not in i)):
+                state = set()
+                continue
+            if i.startswith("buffer_load_dwordx4") and " nt" in i and "lds" not in i:
+                if check:
+                    assert not (names(" ".join(i.split()[2:])) & state), f"{lab}: address of a residual load in a register still in flight: {i}"
+                state |= _vregs(i.split()[1].rstrip(","))
+                continue
+            if check:
+                hit = names(i) & state
+                assert not hit, f"{lab}: `{i}` names residual registers {sorted(hit)} before the wait that makes them valid"
+        return state
+
+    inn = {lab: set() for lab in labels}
+    changed = True
+    while changed:
+        changed = False
+        for lab in labels:
+            out = transfer(lab, inn[lab], False)
+            for t in succ[lab]:
+                if not out <= inn[t]:
+                    inn[t] |= out
+                    changed = True
+    assert any(inn[lab] for lab in labels), "the data flow found no residual register in flight anywhere: the check checks nothing"
+    for lab in labels:
+        transfer(lab, inn[lab], True)
 
 
 def test_attention_resources(attention_asm):

@@ -80,7 +80,9 @@ def _variant_sim(tag, defines):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "wavesim"))
     import build_sim
     from cacophony_amd import _lib
-    lib = Ct.CDLL(build_sim.build(defines=tuple(defines), tag=tag, verbose=False))
+    # CACO_SIM_SKEW_LIB: a sanitizer build of the `skew` variant (tools/wavesim/tsan_check.py --skew --pytest ...)
+    path = os.environ.get("CACO_SIM_SKEW_LIB") if tag == "skew" else None
+    lib = Ct.CDLL(path or build_sim.build(defines=tuple(defines), tag=tag, verbose=False))
     for name, (res, args) in _lib._SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

@@ -68,8 +68,8 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
     replace = dict(replace or {})
     if (replace or defines) and not tag:
         raise ValueError("a variant build needs a tag")
-    if tag and lib == LIB:
-        lib = os.path.join(HERE, f"libcaco_sim_{tag}.so")
+    if tag and lib == LIB:          # a sanitizer build of a variant gets its own library too (it used to overwrite the plain variant's)
+        lib = os.path.join(HERE, f"libcaco_sim_{tag}{'_asan' if asan else ''}{'_tsan' if tsan else ''}{'_ubsan' if ubsan else ''}.so")
     os.makedirs(GEN, exist_ok=True)
     os.makedirs(os.path.join(SHIM, "hip"), exist_ok=True)
     shim = os.path.join(SHIM, "hip", "hip_runtime.h")

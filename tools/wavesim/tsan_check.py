@@ -7,7 +7,7 @@ round-robin over WAVESIM_THREADS workers; those of one worker are ordered, so th
 
     python tools/wavesim/tsan_check.py            # self-test (a planted LDS race and a planted global race must be reported,
                                                   # their barrier-ed twins must not), then the driver of asan_check.py
-    python tools/wavesim/tsan_check.py --pytest [pytest arguments]
+    python tools/wavesim/tsan_check.py [--skew] --pytest [pytest arguments]
                                                   # tests/test_wavesim.py (every kernel and the model paths: decoders, MAE,
                                                   # poolers, ...) with the TSan build loaded through CACO_SIM_LIB
 
@@ -101,6 +101,8 @@ def main():
         args = sys.argv[sys.argv.index("--pytest") + 1:] or ["tests/test_wavesim.py", "-q"]
         env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4", CACO_SIM_LIB=lib,
                    WAVESIM_THREADS="3", OMP_NUM_THREADS="1")
+        if "--skew" in sys.argv[:sys.argv.index("--pytest")]:          # the `skew` variant's own cases on a TSan build of that variant
+            env["CACO_SIM_SKEW_LIB"] = build_sim.build(tsan=True, defines=("-DW8_F32_SKEW",), tag="skew", verbose=False)
         r = subprocess.run([sys.executable, "-m", "pytest", *args], cwd=REPO, env=env, capture_output=True, text=True)
         sys.stdout.write(r.stdout[-1500:])
         s = sites(r.stderr)

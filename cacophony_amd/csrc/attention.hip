@@ -147,6 +147,17 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   // DMA geometry: piece pc of a tile covers LDS bytes [pc*1024, +1024) = linear 16-byte chunks pc*64 + lane.
   // chunk L -> row L / KCH, chunk position L % KCH; the K source chunk is un-swizzled from the position.
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)kv_base, 0, 0x7fffffff, 0x00020000);
+#ifdef ATTN_LEAN
+  // variant `attn_lean`: row, K chunk and V chunk of a piece packed into ONE register (6 + 8 + 8 bits; the uniform k_off / v_off
+  // are added as scalars at use): 3 registers instead of 9 held through the tile loop, 3 more VALU per piece and tile
+  int d_pack[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int L = (wave + i * NW) * 64 + lane;
+    const int r = L / KCH, pos = L % KCH;
+    d_pack[i] = r | ((((pos & ~3) | ((pos & 3) ^ ((r >> 2) & 3))) * 16) << 8) | ((pos * 16) << 16);
+  }
+#else
   int d_row[PPW], d_kcol[PPW], d_vcol[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
@@ -156,15 +167,22 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
     d_kcol[i] = (k_off + (((pos & ~3) | ((pos & 3) ^ ((r >> 2) & 3))) * 8)) * 2;
     d_vcol[i] = (v_off + pos * 8) * 2;
   }
+#endif
   float mreg = 1.f;
   auto issue_tile = [&](int t, int buf) {
     const int key0 = t * KT;
     char* kb = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
+#ifdef ATTN_LEAN
+      const int rowoff = min(key0 + (d_pack[i] & 0xff), S - 1) * ld * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + (wave + i * NW) * 1024), 16, rowoff + ((d_pack[i] >> 8) & 0xff) + k_off * 2, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + K_BYTES + (wave + i * NW) * 1024), 16, rowoff + ((d_pack[i] >> 16) & 0xff) + v_off * 2, 0, 0, 0);
+#else
       const int rowoff = min(key0 + d_row[i], S - 1) * ld * 2;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + (wave + i * NW) * 1024), 16, rowoff + d_kcol[i], 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(kb + K_BYTES + (wave + i * NW) * 1024), 16, rowoff + d_vcol[i], 0, 0, 0);
+#endif
     }
     // wave 0 fetches the tile's key mask; the value is only consumed in finish_tile, so that no wait on it (it would
     // also drain the DMA just issued) lands here
@@ -213,6 +231,13 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       // the 2 QR chains (32-key halves x query blocks) are interleaved so that no MFMA waits on the one issued right
       // before it; each K fragment is read once and used by every query block
+#if defined(ATTN_LEAN) && !defined(WAVESIM)
+      // variant `attn_lean`: the per-lane K row offset is re-derived per tile from an opaque copy of the lane id (5 VALU per tile)
+      // instead of being held through the loop: at 256 VGPRs that register is the one that spilled once the geometry was packed
+      int l31 = lane;
+      asm volatile("" : "+v"(l31));
+      l31 &= 31;
+#endif
       const int kx = (key_perm(l31) >> 2) & 3;          // same for both 32-key halves (32 >> 2 is a multiple of 4)
       const char* kr = kb + key_perm(l31) * RP;
 #ifdef ATTN_KPIPE
@@ -354,6 +379,19 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
   static_assert(NW * 32 * OPITCH <= 2 * BUF, "output staging must fit in the K / V ring");
   char* stage = smem + wave * (32 * OPITCH);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifdef ATTN_LEAN
+  // Variant build `attn_lean` (round 5, written without a GPU; the default kernels stay the round-2 instruction streams):
+  // (1) the lane's staging address is re-derived here from an opaque copy of the lane id instead of `lane & 31` being carried
+  // from the prologue - at 256 VGPRs the two-block kernel spilled exactly that register around its tile loop (8 bytes of scratch;
+  // the thread id it derives from is live through the loop anyway); (2) the
+  // normalisation and bf16 conversion work on register pairs (v_pk_mul_f32 + v_cvt_pk_bf16_f32): the scalar form below compiles
+  // to ~150 surplus v_perm / v_alignbit / v_mov per wave around the conversions (profiles/r4_cpu/epilogue_budget.txt).
+  int lane_e = lane;
+#ifndef WAVESIM
+  asm volatile("" : "+v"(lane_e));       // opaque copy of the lane id (the thread id is live through the loop anyway)
+#endif
+  const int st_off = (lane_e & 31) * OPITCH + (lane_e >> 5) * 8;
+#endif
 #pragma unroll
   for (int x = 0; x < QR; ++x) {
     const int qx = q0 + 32 * x;
@@ -365,9 +403,20 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 v;
+#ifdef ATTN_LEAN
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 y = f32x2{o[x][dt][g * 4 + e], o[x][dt][g * 4 + e + 1]} * f32x2{inv, inv};
+          v[e] = (bf16_t)y[0];
+          v[e + 1] = (bf16_t)y[1];
+        }
+        *reinterpret_cast<bf16x4*>(stage + st_off + (dt * 32 + g * 8) * 2) = v;
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[x][dt][g * 4 + e] * inv);
         *reinterpret_cast<bf16x4*>(stage + l31 * OPITCH + (dt * 32 + g * 8 + 4 * hf) * 2) = v;
+#endif
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     CACO_WAVE_LDS_SYNC();

@@ -222,6 +222,22 @@ def test_attention_resources(attention_asm):
     assert loop_mfma == 48, loop_mfma
 
 
+def test_attention_lean_variant_budget(tmp_path_factory):
+    """Variant build `attn_lean` (-DATTN_LEAN; the default attention kernels stay the round-2 instruction streams): no attention
+    kernel spills, the two-block kernel's output epilogue carries no v_perm / v_alignbit around its bf16 conversions and is at
+    least 120 instructions shorter per wave, and its tile loop is unchanged in matrix work."""
+    base_k, base_m = _kernels(_assembly("attention.hip", tmp_path_factory))
+    lean_k, lean_m = _kernels(_assembly("attention.hip", tmp_path_factory, ["-DATTN_LEAN"]))
+    assert lean_m and all(m["scratch"] == 0 for m in lean_m.values()), {k[-40:]: m for k, m in lean_m.items() if m["scratch"]}
+    audio = _find(lean_m, "attention_kernelILi96ELb0ELi4ELi2ELb0E")
+    assert lean_m[audio]["vgpr"] <= 256 and lean_m[audio]["occ"] == 2
+    n = lambda ks, name: sum(len(b) for b in ks[name])
+    ops = Counter(i.split()[0] for b in lean_k[audio] for i in b)
+    assert ops["v_perm_b32"] == 0 and ops["v_alignbit_b32"] == 0, ops
+    assert n(base_k, audio) - n(lean_k, audio) >= 120, (n(base_k, audio), n(lean_k, audio))
+    assert sum(1 for b in lean_k[audio] for i in b if "v_mfma_f32_32x32x16_bf16" in i) == 48
+
+
 def test_no_kernel_of_the_library_spills_beyond_the_known_few(tmp_path_factory):
     """Every kernel of every translation unit: scratch (= spilled registers) is 0, except the two known cases - the two-block audio
     attention kernel (8 bytes, outside its loop) and the experimental four-wave GEMM gemm_w4q (<= 128 bytes, outside its K-loop; never a default kernel)."""

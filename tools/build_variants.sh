@@ -13,6 +13,13 @@ rm -rf "$(dirname "$TMPSRC")"
 # round 4: K fragment reads of the score phase pinned 1 / 2 steps ahead of their MFMAs (the default build's ISA waits lgkmcnt(0) after
 # every read there: one fragment buffer at 256 VGPRs); same registers, same results (simulator)
 # (round 5: attn_sc1, ln_2rows and a_sc1 are no longer built - no written hypothesis behind them)
+# round 5 (CPU part): the two-block attention kernel without its spilled register (geometry of the DMA pieces packed
+# 9 -> 3 registers, K row offset re-derived per tile: 0 bytes of scratch in every attention kernel) and with the output epilogue's
+# normalisation + bf16 conversion on register pairs (-156 instructions per wave, no v_perm / v_alignbit); bitwise the default's
+# results on the simulator.  Prediction: attention 0.264 -> 0.255-0.262 ms (3 % fewer instructions in an issue-bound kernel, ~2 % more
+# in its tile loop); attn_lean_k2 adds kpipe2's pinned K reads on top.
+bash tools/build_variant.sh attn_lean attention.hip -DATTN_LEAN
+bash tools/build_variant.sh attn_lean_k2 attention.hip -DATTN_LEAN -DATTN_KPIPE=2
 bash tools/build_variant.sh kpipe1 attention.hip -DATTN_KPIPE=1
 bash tools/build_variant.sh kpipe2 attention.hip -DATTN_KPIPE=2
 bash tools/build_variant.sh attn_nt attention.hip -DATTN_ST_AUX=2

@@ -50,10 +50,8 @@ if [ "$PART" = bisect ]; then
   (timeout 900 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_arms.json" default r2 classic libm_erf r2addr 2>&1 | tail -30) | tee "$OUT/ab_arms.txt"
 fi
 # compile-time variants prepared by tools/build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
-if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/null 2>&1; then
+if want variants && ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>&1; then
   # a variant library under the product's own op tests (CACO_ALLOW_VARIANT_LIB: the suite otherwise refuses any library but the product's)
-  (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_fastpass.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "attention" 2>&1 | tail -3) > "$OUT/pytest_fastpass.txt"
-  cat "$OUT/pytest_fastpass.txt"
   (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_f32direct.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or guard" 2>&1 | tail -3) > "$OUT/pytest_f32direct.txt"
   cat "$OUT/pytest_f32direct.txt"
   # round 5: the skewed-row-block fp32 epilogue under the product's own GEMM cases (the chip-filling fp32 + residual shapes of
@@ -65,7 +63,7 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_fastpass.so >/dev/nul
   (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_attn_lean.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "attention" 2>&1 | tail -3) > "$OUT/pytest_attn_lean.txt"
   cat "$OUT/pytest_attn_lean.txt"
   # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated order)
-  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default skew skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct f32direct16 f32direct4 classic_f32direct attn_lean attn_lean_k2 kpipe1 kpipe2 fastpass attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
+  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default skew skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
   (CACO_PINGPONG=1 timeout 600 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_variants_pingpong.json" default st_plain ln_nt a_nt 2>&1 | tail -20) | tee "$OUT/ab_variants_pingpong.txt"     # ping-pong x store policy
 fi
 # PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)

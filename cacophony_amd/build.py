@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcaco_hip.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["api.hip", "gemm.hip", "gemm_x.hip", "gemm_w8.hip", "gemm_w4q.hip", "gemm_w4h.hip", "attention.hip", "attention_small.hip", "norm.hip", "pool.hip", "mel.hip", "topk.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "gemm_w8_epilogue.h", "gemm_w8_common.h", "gemm_w8_ktile.inc", "gemm_w8_skew.inc", "gemm_w8_skew_ktile.inc", "gemm_w4q_ktile.inc", "gemm_w4h_ktile.inc", os.path.join(INCLUDE, "caco_hip.h")]
+HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "gemm_w8_epilogue.h", "gemm_w8_common.h", "gemm_w8_ktile.inc", "gemm_w8_skew.inc", "gemm_w8_skew_ktile.inc", "gemm_w8_epilogue_direct.inc", "attention_kpipe.inc", "gemm_w4q_ktile.inc", "gemm_w4h_ktile.inc", os.path.join(INCLUDE, "caco_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=fast"]

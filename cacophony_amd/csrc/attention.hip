@@ -241,37 +241,7 @@ __device__ __forceinline__ void attention_body(const bf16_t* __restrict__ qp_, i
       const int kx = (key_perm(l31) >> 2) & 3;          // same for both 32-key halves (32 >> 2 is a multiple of 4)
       const char* kr = kb + key_perm(l31) * RP;
 #ifdef ATTN_KPIPE
-      // EXPERIMENT (round 4, variant build -DATTN_KPIPE=depth, never the default): the K fragment reads pinned `depth` steps ahead
-      // of the MFMAs that consume them.  In the default build's ISA every ds_read_b128 of this phase is followed by
-      // s_waitcnt lgkmcnt(0) and its two MFMAs - at 256 VGPRs the scheduler keeps one fragment buffer, so each step exposes the
-      // LDS latency to this wave (the P fragments of the previous tile are dead here: their registers can hold the look-ahead).
-      {
-        constexpr int STEPS = KS * 2, AH = ATTN_KPIPE > 0 ? ATTN_KPIPE : 2;
-        auto k_read = [&](int step) {
-          const int ks = step >> 1, st = step & 1;
-          const int c = ks * 2 + hf;
-          const int coff = ((c & ~3) | ((c & 3) ^ kx)) << 4;
-          return *reinterpret_cast<const bf16x8*>(kr + st * 32 * RP + coff);
-        };
-        bf16x8 kfb[AH + 1];
-#pragma unroll
-        for (int i = 0; i < AH; ++i) kfb[i] = k_read(i);
-#pragma unroll
-        for (int step = 0; step < STEPS; ++step) {
-          const int ks = step >> 1, st = step & 1;
-          if (step + AH < STEPS) kfb[(step + AH) % (AH + 1)] = k_read(step + AH);
-#pragma unroll
-          for (int x = 0; x < QR; ++x)
-            s[x][st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[step % (AH + 1)], qf[x][ks], ks == 0 ? zero16 : s[x][st], 0, 0, 0);
-        }
-        // pin the order: AH reads, then per step one read followed by the step's QR MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, AH, 0);
-#pragma unroll
-        for (int step = 0; step < STEPS; ++step) {
-          if (step + AH < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, QR, 0);
-        }
-      }
+#include "attention_kpipe.inc"
 #else
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {

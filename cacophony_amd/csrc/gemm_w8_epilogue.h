@@ -181,45 +181,7 @@ __device__ __forceinline__ void w16_epilogue(const f32x4 (&acc)[8][4], const Gem
     int rowb = p.ldc * 4;
     W8_EPI_LOCAL(rowb);
 #ifdef W8_F32_DIRECT
-    // EXPERIMENT (round 4, written without a GPU; variant build -DW8_F32_DIRECT[=depth], never the default): the plain fp32
-    // forms (bias; bias + residual) straight from the accumulator layout.  A lane owns 4 consecutive n = 16 bytes of one row,
-    // the four lanes l16 + 16 * lq of a row cover a 64-byte segment: a wave instruction moves 16 rows x 64 B with no LDS
-    // transposition at all (the 32 ds_write_b128 + 32 ds_read_b128 and both intra-wave hand-offs per tile disappear), and the
-    // residual is added in place, so D residual blocks can be in flight in the 64 VGPRs the dead operand fragments leave
-    // free - 12 KB per wave instead of the slab form's 4 KB.  What it costs: 64-byte instead of 128-byte row segments (twice
-    // the requests per byte; two instructions share every 128-byte line).  The 32x32x16 layout's direct form (8-byte pieces,
-    // 32 rows per instruction) measured 30-40 % slower on bf16 outputs in round 1; this is 16-byte pieces of fp32 rows.
-    // Hypotheses it separates: if the fp32 epilogue's 44 k cycles are a per-wave latency chain (4 KB in flight), this form
-    // shortens them by up to the depth ratio; if they are the HBM burst of 256 CUs, it changes nothing.
-    if constexpr (MODE == 1 || MODE == 2) {
-      constexpr int D = (W8_F32_DIRECT > 1) ? W8_F32_DIRECT : 12;
-      static_assert(D >= 1 && D <= 16, "residual blocks in flight");
-      const int bytes_d = rows > 0 ? (rows - 1) * rowb + 256 : 0;
-      const __amdgpu_buffer_rsrc_t out_d =
-          __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.out) + mw * p.ldc + nw, 0, bytes_d, 0x00020000);
-      const __amdgpu_buffer_rsrc_t res_d = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(MODE == 2 ? p.resid : reinterpret_cast<const float*>(p.out)) + mw * p.ldc + nw, 0, MODE == 2 ? bytes_d : 0, 0x00020000);
-      const int voff_d = l16 * rowb + lq * 16;                 // block (ib, jb): + ib * 16 rows (per-lane part) + jb * 64 bytes
-      f32x4 bb[4];                                             // the lane's 4 x 4 bias columns, fetched ONCE and first: a bias
-#pragma unroll                                                 // load inside the block loop sits in the same in-order vmcnt queue
-      for (int jb = 0; jb < 4; ++jb) bb[jb] = *reinterpret_cast<const f32x4*>(p.bias + nw + lq * 4 + jb * 16);   // as the residual
-      u32x4 rd[D];                                             // loads and turns every wait into vmcnt(0)
-      if constexpr (MODE == 2) {
-#pragma unroll
-        for (int b = 0; b < D; ++b) rd[b] = __builtin_amdgcn_raw_buffer_load_b128(res_d, voff_d + (b >> 2) * 16 * rowb, (b & 3) * 64, W8_LD_AUX);
-      }
-#pragma unroll
-      for (int b = 0; b < 32; ++b) {
-        const int ib = b >> 2, jb = b & 3;
-        f32x4 v = acc[ib][jb] + bb[jb];
-        if constexpr (MODE == 2) {
-          v += __builtin_bit_cast(f32x4, rd[b % D]);
-          if (b + D < 32) rd[b % D] = __builtin_amdgcn_raw_buffer_load_b128(res_d, voff_d + ((b + D) >> 2) * 16 * rowb, ((b + D) & 3) * 64, W8_LD_AUX);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_d, voff_d + ib * 16 * rowb, jb * 64, W8_ST_AUX_F32);
-      }
-      return;
-    }
+#include "gemm_w8_epilogue_direct.inc"
 #endif
     const int bytes = rows > 0 ? (rows - 1) * rowb + 256 : 0;
     const bool has_resid = MODE ? (MODE == 2 || MODE == 4 || MODE == 5) : p.resid != nullptr;

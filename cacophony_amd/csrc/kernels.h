@@ -102,7 +102,9 @@ int copy_rows(const float* src, float* dst, int batch, int src_seq, int dst_seq,
 
 // attention.hip
 // qkv: bf16 [batch*seq, ld], Q at column 0, K at k_off, V at v_off (head h = columns h*head_dim.. of each)
-// order: 0 = clip b on XCD b % 8 (default); 1 / 2 = XCD x serves clips [x * B/8, (x + 1) * B/8), first to last / last to first
+// order: 0 = clip b on XCD b % 8 (default); 1 / 2 = XCD x serves clips [x * B/8, (x + 1) * B/8), first to last / last to first.
+// A non-zero order is honoured ONLY by the non-causal head_dim 96 kernels (the audio tower, where the ping-pong traversal of
+// api.hip asks for it); every other instantiation is compiled without the argument's use and keeps order 0.
 int attention(const bf16_t* qkv, int ld, int k_off, int v_off, const float* key_mask, int batch, int seq, int heads,
               int head_dim, int causal, bf16_t* out, hipStream_t st, int order = 0);
 // kv_batch_rows: rows between the first keys of two consecutive clips in `kv` (0 = seq; larger for a KV cache)

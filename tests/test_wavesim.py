@@ -149,6 +149,26 @@ def test_gemm_skewed_falls_back_where_it_does_not_apply(skew_sim, sim):
         assert torch.equal(a, b), (M, N, K)
 
 
+def test_gemm_skewed_other_team_geometries(skew_sim):
+    """The team mapping at other workgroup counts (the CU count is read once per process: a subprocess with WAVESIM_CUS = 8 and 24):
+    2 and 8 teams of 3 workgroups with idle workgroups left over, a single-column shape (teams of one), teams with unequal panel counts."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, math, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_wavesim import _variant_sim, _skew_case\n"
+        "from tests import simlib\n"
+        "lib = _variant_sim('skew', ['-DW8_F32_SKEW'])\n"
+        "for M, N, K in ((2048, 768, 768), (2100, 768, 640), (3000, 256, 1024)):\n"
+        "    out, ref, ref64 = _skew_case(lib, M, N, K, 60)\n"
+        "    err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()\n"
+        "    assert err <= 3e-6, (M, N, K, err)\n"
+        "print('OK')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for cus in ("8", "24"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WAVESIM_CUS=cus), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (cus, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_gemm_skewed_weak_wait_is_caught():
     """The skewed kernel waits for its residual registers itself (inline-assembly loads the compiler's wait-count pass does not
     see).  On the simulator such a load lands in its destination variable at the covering wait; a build whose wait leaves ONE

@@ -16,16 +16,17 @@ export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 if want truth; then
 echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
-(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > "$OUT/pytest_gpu.txt"                  # the product: default path only
+(timeout 1200 python -m pytest tests -m gpu -q -rfE --tb=short 2>&1 | tail -120) > "$OUT/pytest_gpu.txt"                  # the product: default path only
 tail -3 "$OUT/pytest_gpu.txt"
-(CACO_RUN_EXPERIMENTAL=1 timeout 900 python -m pytest tests -m "gpu and experimental" -q 2>&1 | tail -40) > "$OUT/pytest_gpu_experimental.txt"   # never-default kernels, opt-in switches (no -x)
-tail -3 "$OUT/pytest_gpu_experimental.txt"
 (timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > "$OUT/smoke.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
 bash tools/profile_bench.sh r5_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
 cp gpurun_out/prof_r5_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+# the experimental cases last: the product's record (pytest, smoke, bench, kernel stats) must exist before anything optional runs
+(CACO_RUN_EXPERIMENTAL=1 timeout 900 python -m pytest tests -m "gpu and experimental" -q 2>&1 | tail -40) > "$OUT/pytest_gpu_experimental.txt"   # never-default kernels, opt-in switches (no -x)
+tail -3 "$OUT/pytest_gpu_experimental.txt"
 fi
 if want ab; then
 # every run-time switch against the default, interleaved inside ONE process (caco_set_switch), with the flip / delete verdict

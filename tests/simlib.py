@@ -63,10 +63,10 @@ def sync_switches(lib=None) -> None:
         lib.caco_set_switch(name.encode(), int(v) if v not in (None, "") else _SWITCH_DEFAULTS.get(name, 0))
 
 
-def check(status: int, what: str = "") -> None:
+def check(status: int, what: str = "", lib=None) -> None:
     if status == 0:
         return
-    msg = load().caco_last_error().decode("utf-8", "replace")
+    msg = (lib or load()).caco_last_error().decode("utf-8", "replace")
     if status == _lib.CACO_ERR_INVALID:
         raise ValueError(f"{what}: {msg}")
     raise RuntimeError(f"{what}: {msg} (status {status})")
@@ -84,8 +84,8 @@ class SimModel:
     """The construction / weight-loading sequence of cacophony_amd.model._HipModel against the simulator library, plus thin
     wrappers of the forward entry points on torch CPU tensors."""
 
-    def __init__(self, audio_config, text_config, caco_config, mae_decoder_layers: int = 0, caption_decoder_layers: int = 0):
-        self.lib = load()
+    def __init__(self, audio_config, text_config, caco_config, mae_decoder_layers: int = 0, caption_decoder_layers: int = 0, lib=None):
+        self.lib = lib if lib is not None else load()          # lib: a variant build of the simulator library (tests/test_wavesim.py)
         self.a, self.t, self.c = audio_config, text_config, caco_config
         cfg = _lib.CacoConfigC()
         self.lib.caco_default_config(C.byref(cfg))

@@ -169,6 +169,30 @@ def test_gemm_skewed_other_team_geometries(skew_sim):
         assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (cus, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_audio_layer_with_skewed_gemms_matches_the_default_build(skew_sim, sim, tiny_state):
+    """One full-width audio layer at batch 8 with the persistent GEMM forced on (CACO_W8_MIN_TILES = 1): out-proj (K = 768, D = 1)
+    and fc2 (K = 3072, D = 6) run on the skewed kernel inside the model's launch sequence - in-place residual stream, the real
+    strides.  The embeddings must equal the default build's to fp32 rounding, and differ from them in bits (else it fell back)."""
+    from dataclasses import replace
+    a, t, cc = C.tiny_configs(2)
+    a = replace(a, num_layers=1)
+    state = {k: v for k, v in tiny_state.items() if ".layers.1." not in k and "layers_1" not in k}
+    wav = torch.from_numpy(synth.make_waveforms(8, start=40))
+    embs = []
+    for lib in (sim, skew_sim):
+        prev = lib.caco_get_switch(b"CACO_W8_MIN_TILES")
+        assert lib.caco_set_switch(b"CACO_W8_MIN_TILES", 1) == 0
+        try:
+            m = simlib.SimModel(a, None, cc, lib=lib).load_state_dict({k: v for k, v in state.items() if k.startswith(("audio_", "logit_scale"))})
+            embs.append(m.encode_audio(wav).numpy())
+        finally:
+            lib.caco_set_switch(b"CACO_W8_MIN_TILES", prev)
+    base, skew = embs
+    assert not np.array_equal(base, skew), "identical bits: the skewed kernel did not run inside the model"
+    assert np.abs(base - skew).max() < 5e-6 * np.abs(base).max() + 1e-6
+    assert cosine_rows(base, skew).min() > 0.999999
+
+
 def test_gemm_skewed_weak_wait_is_caught():
     """The skewed kernel waits for its residual registers itself (inline-assembly loads the compiler's wait-count pass does not
     see).  On the simulator such a load lands in its destination variable at the covering wait; a build whose wait leaves ONE

@@ -57,6 +57,32 @@ def fuzz_gemm(sim, rng, log):
     log.append(f"gemm tile {tile} M {M} N {N} K {K} act {act}")
 
 
+def fuzz_skew(sim, rng, log):
+    """Shapes that reach the skewed-row-block fp32 + residual kernel when the library is the `skew` variant build (CACO_SIM_LIB =
+    tools/wavesim/libcaco_sim_skew.so; on the default build the same cases run gemm_bf16_w8): at least 16 tiles on the simulator's
+    16 CUs, K >= 576, ragged and whole M, in place or with a separate residual, guard rows on both sides of the output."""
+    N = int(rng.choice([256, 512, 768, 1024]))
+    K = 64 * int(rng.choice([9, 10, 12, 13, 16, 17, 24]))
+    panels = int(np.ceil(16 / (N // 256))) + int(rng.integers(0, 6))
+    M = panels * 256 - int(rng.choice([0, 0, 1, 17, 100, 255]))
+    a = torch.randn(M, K).bfloat16()
+    w = (torch.randn(N, K) / math.sqrt(K)).bfloat16()
+    bias, x0 = torch.randn(N), torch.randn(M, N)
+    ref = a.double() @ w.double().T + bias.double() + x0.double()
+    inplace = rng.random() < 0.6
+    buf = torch.full((M + 8, N), GUARD)
+    buf[4:4 + M] = x0 if inplace else 0.0
+    out = buf[4:4 + M]
+    sim.caco_set_gemm_tile(8256)
+    rc = sim.caco_op_gemm_bf16_f32out(P(a), P(w), P(bias), P(out) if inplace else P(x0), M, N, K, P(out), None)
+    sim.caco_set_gemm_tile(256)
+    assert rc == 0, (sim.caco_last_error(), M, N, K)
+    err = ((out.double() - ref).abs() / (ref.abs() + 1.0)).max().item()
+    assert err < 4e-6 * max(1.0, K / 1024), ("skew gemm f32", M, N, K, inplace, err)
+    assert (buf[:4] == GUARD).all() and (buf[4 + M:] == GUARD).all(), ("skew gemm f32 wrote outside its rows", M, N, K)
+    log.append(f"skew M {M} N {N} K {K} inplace {inplace} err {err:.2e}")
+
+
 def attn_ref(q, k, v, mask, heads, hd, causal):
     B, Sq, H = q.shape
     S = k.shape[1]
@@ -228,7 +254,7 @@ def fuzz_model(sim, rng, log):
     log.append(desc + f" cos {ca:.5f} {ct:.5f}")
 
 
-KINDS = {"model": fuzz_model, "gemm": fuzz_gemm, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "mel": fuzz_mel, "topk": fuzz_topk}
+KINDS = {"model": fuzz_model, "gemm": fuzz_gemm, "skew": fuzz_skew, "attention": fuzz_attention, "layernorm": fuzz_layernorm, "mel": fuzz_mel, "topk": fuzz_topk}
 
 
 def run(cases, seed, kinds, verbose=False):

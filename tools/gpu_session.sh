@@ -1,12 +1,15 @@
 #!/bin/bash
-# The first GPU call once the pool reopens (round 3 wrote everything below without one):
-#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh truth'      (then `ab`, `variants`, `pmc`: one call each, ~20-25 min)
-#   bash tools/gpu_session.sh all                                    everything in one call (~60 min); `bisect` is never part of `all`
-# 1. truth: hardware record of the DEFAULT build: pytest -m gpu (default path), the experimental cases apart, smoke, bench,
-#    rocprofv3 kernel stats  -> gpurun_out/r4_v0/   (copy to profiles/r4_v0/)
+# The GPU sessions that rounds 3-5 prepared without a GPU (tools/README.md has the runbook):
+#   gpurun --timeout 3000 -- 'bash tools/gpu_session.sh truth'                       then, one call each:
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh ab'       bash tools/gpurun_variants.sh --timeout 2400 -- 'bash tools/gpu_session.sh variants'
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh pmc'      bash tools/gpurun_variants.sh --timeout 1500 -- 'bash tools/gpu_session.sh bisect'
+# 1. truth: hardware record of the DEFAULT build: pytest -m gpu (default path), smoke, bench, rocprofv3 kernel stats, then the
+#    experimental cases  -> gpurun_out/r5_v0/   (copy to profiles/r5_v0/)
 # 2. ab: every run-time switch against the default, interleaved in one process (tools/ab_switches.py: flip / delete verdicts),
 #    rocprofv3 kernel stats with the fusions on, GEMM kernels per shape (w8 / w4q / w4h / x / 128), fc1 inside chains
-# 3. variants: compile-time A/B libraries (tools/build_variants.sh)      4. pmc: SQ / TCC counters, HBM traffic of fc1
+# 3. variants: compile-time A/B libraries (tools/build_variants.sh; they travel only with tools/gpurun_variants.sh), the skew and
+#    attn_lean libraries under the product's own tests, tools/check_predictions.py      4. pmc: SQ / TCC counters, HBM traffic of fc1
+# 5. bisect (never part of `all`): the arms r2 / classic / libm_erf / r2addr under the GEMM cases, after a red truth run
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}

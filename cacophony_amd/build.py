@@ -24,7 +24,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-Wno-unused-variable", "-ffp-contract=fast"]
 
 
-EXTRA_FLAGS = {}      # per-source extra hipcc flags
+# Per-source extra hipcc flags: where a variant build that WON its hardware A/B becomes the default - e.g.
+# {"gemm_w8.hip": ["-DW8_F32_SKEW"], "attention.hip": ["-DATTN_LEAN"]} (tools/README.md "Flipping a variant").  The simulator build
+# (tools/wavesim/build_sim.py) and tests/test_codegen_budget.py read the same table, so the CPU checks follow a flip.
+EXTRA_FLAGS = {}
 
 
 def _hipcc() -> str:

@@ -14,6 +14,8 @@ from collections import Counter
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in __import__("sys").path:
+    __import__("sys").path.insert(0, REPO)
 CSRC = os.path.join(REPO, "cacophony_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fno-gpu-rdc -ffp-contract=fast --cuda-device-only -S".split()
@@ -23,7 +25,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 
 def _assembly(src, tmp_path_factory, defines=()):
     out = os.path.join(str(tmp_path_factory.mktemp("isa")), src.replace(".hip", ".s"))
-    r = subprocess.run([HIPCC, *FLAGS, *defines, "-I", os.path.join(REPO, "include"), os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
+    from cacophony_amd.build import EXTRA_FLAGS          # the product build's per-source flags (a flipped variant)
+    r = subprocess.run([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), *defines, "-I", os.path.join(REPO, "include"), os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return open(out).read()
 

@@ -96,6 +96,10 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
                 f.write(t)
     headers = headers + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
 
+    sys.path.insert(0, REPO)
+    from cacophony_amd.build import EXTRA_FLAGS as product_extra          # -D flags a flipped variant added to the product build
+    headers = headers + [os.path.join(REPO, "cacophony_amd", "build.py")]
+
     def one(src):
         path = src if os.path.isabs(src) else os.path.join(CSRC, src)
         base = os.path.basename(path)
@@ -113,7 +117,7 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         else:
             gen = path
         san = ["-fsanitize=thread"] if (tsan and base.endswith(".hip")) else []
-        cmd = [CXX, *flags, *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
+        cmd = [CXX, *flags, *[f for f in product_extra.get(base, []) if f.startswith("-D")], *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{base}:\n{r.stdout}\n{r.stderr}")

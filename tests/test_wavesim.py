@@ -129,7 +129,7 @@ def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
     out, ref, ref64 = _skew_case(skew_sim, M, N, K, 40)
     err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
     err32 = ((ref.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
-    # measured against float64, as a fraction of 1 + |ref|: 1.8e-6 .. 2.4e-6 for K <= 1024 and 5.9e-6 at K = 3072; gemm_bf16_w8 on
+    # measured against float64, as a fraction of 1 + |ref|: 1.8e-6 .. 2.4e-6 for K <= 1024 and 4.2e-6 at K = 3072; gemm_bf16_w8 on
     # the same cases 1.8e-6 resp. 4.8e-6 (fp32 accumulation of K products either way; the K-tiles are summed in a rotated order
     # here), torch's own fp32 product 1.1e-6
     assert err <= (3e-6 if K <= 1024 else 7e-6), f"max error {err:.3e} relative to 1 + |ref| (torch fp32 itself: {err32:.3e})"
@@ -147,6 +147,18 @@ def test_gemm_skewed_falls_back_where_it_does_not_apply(skew_sim, sim):
         a, _, _ = _skew_case(skew_sim, M, N, K, 50)
         b, _, _ = _skew_case(sim, M, N, K, 50)
         assert torch.equal(a, b), (M, N, K)
+
+
+def test_gemm_skewed_linear_panel_list(sim):
+    """The linear form of the same kernel (-DW8_SKEW_LINEAR, variant `skew_lin`: first-period blocks idle, a tail period at the
+    end) - the other arm of the A/B against the circular panel list of `skew`."""
+    lin = _variant_sim("skew_lin", ["-DW8_F32_SKEW", "-DW8_SKEW_LINEAR"])
+    for M, N, K in ((2000, 768, 768), (2304, 512, 3072), (1800, 768, 640)):
+        out, ref, ref64 = _skew_case(lin, M, N, K, 40)
+        err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
+        assert err <= (3e-6 if K <= 1024 else 7e-6), (M, N, K, err)
+        base, _, _ = _skew_case(sim, M, N, K, 40)
+        assert not torch.equal(base, out)
 
 
 def test_gemm_skewed_other_team_geometries(skew_sim):

@@ -42,11 +42,12 @@ bash tools/build_variant.sh classic gemm_w8.hip -DW8_CLASSIC
 bash tools/build_variant.sh libm_erf gemm.hip,gemm_x.hip,gemm_w8.hip,gemm_w4q.hip,gemm_w4h.hip -DCACO_LIBM_ERF
 bash tools/build_variant.sh r2addr gemm_w8.hip -DW8_R2_ADDR
 # round 5: the fp32 + residual epilogue UNDER the K-loop (csrc/gemm_w8_skew.inc: skewed row blocks, one 16-row block completing every
-# D K-tiles; simulator-checked, 242 VGPRs, 0 scratch).  Predictions, stated before any measurement: out-proj 0.23 -> <= 0.21 ms,
-# fc2 0.54 -> <= 0.46 ms, step -1.0 .. -1.3 ms of 28.  skew_d2: at most 2 K-tiles between events (fc2: the events of a period
-# bunch in its first 16 K-tiles, the launch's tail shrinks from 43 to 15 K-tiles) - which of the two costs less is the question.
+# D K-tiles; simulator-checked, 246 VGPRs, 0 scratch).  Predictions, stated before any measurement: skew (circular panel list: no
+# launch tail) out-proj 0.23 -> <= 0.20 ms, fc2 0.54 -> <= 0.41 ms, step -1.8 .. -2.2 ms of 28; skew_lin (linear list: 7D + 1 extra
+# K-tiles per launch) <= 0.21 / <= 0.46 ms, step -1.0 .. -1.3; skew_d2 (at most 2 K-tiles between events) within 0.02 ms of skew.
 bash tools/build_variant.sh skew gemm_w8.hip -DW8_F32_SKEW
 bash tools/build_variant.sh skew_d2 gemm_w8.hip -DW8_F32_SKEW -DW8_SKEW_D=2
+bash tools/build_variant.sh skew_lin gemm_w8.hip -DW8_F32_SKEW -DW8_SKEW_LINEAR
 # ... and the arm that changes everything at once: the whole library of commit cccbeef, the last binary an MI355X has run
 bash tools/build_r2_arm.sh
 python -m cacophony_amd.build --force >/dev/null

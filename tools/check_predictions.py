@@ -14,15 +14,18 @@ LAUNCHES = 12          # audio layers: every audio.* GEMM / attention stage is 1
 PREDICTIONS = [
     ("default", "audio.gemm_qkv", "round 4: peeled first K-tile + packed bias epilogue, 0.38 -> ~0.33 ms", 0.0, 0.345, "profiles/r4_cpu/epilogue_budget.txt"),
     ("default", "audio.gemm_fc1", "round 4: peeled first K-tile, 0.585 -> ~0.545 ms", 0.0, 0.56, "profiles/r4_cpu/epilogue_budget.txt"),
-    ("skew", "audio.gemm_out", "round 5: epilogue under the K-loop, 0.23 -> <= 0.21 ms", 0.0, 0.21, "csrc/gemm_w8_skew.inc"),
-    ("skew", "audio.gemm_fc2", "round 5: epilogue under the K-loop, 0.54 -> <= 0.46 ms", 0.0, 0.46, "csrc/gemm_w8_skew.inc"),
-    ("skew_d2", "audio.gemm_fc2", "round 5: events bunched (D = 2), shorter tail: within 0.02 ms of skew either way", 0.0, 0.48, "tools/build_variants.sh"),
+    ("skew", "audio.gemm_out", "round 5: epilogue under the K-loop, circular panel list, 0.23 -> <= 0.20 ms", 0.0, 0.20, "csrc/gemm_w8_skew.inc"),
+    ("skew", "audio.gemm_fc2", "round 5: epilogue under the K-loop, circular panel list, 0.54 -> <= 0.41 ms", 0.0, 0.41, "csrc/gemm_w8_skew.inc"),
+    ("skew_lin", "audio.gemm_out", "round 5: linear panel list (8 extra K-tiles per launch), 0.23 -> <= 0.21 ms", 0.0, 0.21, "csrc/gemm_w8_skew.inc"),
+    ("skew_lin", "audio.gemm_fc2", "round 5: linear panel list (43 extra K-tiles per launch), 0.54 -> <= 0.46 ms", 0.0, 0.46, "csrc/gemm_w8_skew.inc"),
+    ("skew_d2", "audio.gemm_fc2", "round 5: events bunched (D = 2): within 0.02 ms of skew", 0.0, 0.43, "tools/build_variants.sh"),
     ("attn_lean", "audio.attention", "round 5: no spill, epilogue on register pairs, 0.264 -> 0.255-0.262 ms", 0.0, 0.262, "tools/build_variants.sh"),
 ]
 # step-level predictions: (variant, delta vs default in ms: lower, upper, text)
 STEP = [
     ("classic", +0.2, +1.1, "round 4: the default (peeled / packed) beats `classic` by 0.2 .. 1.1 ms per step"),
-    ("skew", -1.3, -1.0, "round 5: skew beats the default by 1.0 .. 1.3 ms per step (if the power cap returns cycles as time)"),
+    ("skew", -2.2, -1.8, "round 5: skew (circular) beats the default by 1.8 .. 2.2 ms per step (if the power cap returns cycles as time)"),
+    ("skew_lin", -1.3, -1.0, "round 5: skew_lin beats the default by 1.0 .. 1.3 ms per step"),
 ]
 
 

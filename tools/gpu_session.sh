@@ -60,19 +60,19 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>
   cat "$OUT/pytest_f32direct.txt"
   # round 5: the skewed-row-block fp32 epilogue under the product's own GEMM cases (the chip-filling fp32 + residual shapes of
   # test_gemm_persistent_multi_tile_pipeline reach it; everything else falls back to gemm_bf16_w8) and the model goldens
-  for v in skew skew_d2; do
+  for v in skew skew_lin; do
     (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_$v.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or chip_filling or full_batch" 2>&1 | tail -3) > "$OUT/pytest_$v.txt"
     echo "== $v"; cat "$OUT/pytest_$v.txt"
   done
   (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_attn_lean.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "attention" 2>&1 | tail -3) > "$OUT/pytest_attn_lean.txt"
   cat "$OUT/pytest_attn_lean.txt"
   # isolated launches of the two fp32 + residual shapes: default, skew, skew_d2 (twice, alternating: the box's own spread)
-  { for rep in 1 2; do for v in default skew skew_d2 f32direct; do
+  { for rep in 1 2; do for v in default skew skew_lin skew_d2 f32direct; do
       if [ $v = default ]; then unset CACO_LIB_PATH; else export CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_$v.so; fi
       echo "== $v (rep $rep)"; CACO_ALLOW_VARIANT_LIB=1 timeout 120 python tools/gemm_bench.py --only out,fc2 --iters 20
     done; done; unset CACO_LIB_PATH; } > "$OUT/gemm_f32r_isolated.txt" 2>&1; cat "$OUT/gemm_f32r_isolated.txt"
   # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated order)
-  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default skew skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
+  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default skew skew_lin skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
   python tools/check_predictions.py "$OUT/ab_variants.json" "$OUT/bench.json" 2>&1 | tee "$OUT/predictions_vs_measured.txt"      # stated before, checked after
   (CACO_PINGPONG=1 timeout 600 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_variants_pingpong.json" default st_plain ln_nt a_nt 2>&1 | tail -20) | tee "$OUT/ab_variants_pingpong.txt"     # ping-pong x store policy
 fi

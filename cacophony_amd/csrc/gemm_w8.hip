@@ -269,8 +269,8 @@ int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
 #ifdef W8_F32_SKEW
     if (p.resid) {
       int num_cu = 0;
-      CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(&gemm_bf16_w8s_kernel), W_SMEM, &num_cu));
-      if (gemm_bf16_w8s_ok(p, num_cu / 8 * 8)) return launch_w8s(p, st);
+      CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(&gemm_bf16_w8s_kernel<false>), W_SMEM, &num_cu));
+      if (gemm_bf16_w8s_ok(p, num_cu / 8 * 8)) return launch_w8s<false>(p, st);
     }
 #endif
     if (p.resid) return launch_w8<EPI_F32, ACT_NONE, 2>(p, st);
@@ -280,8 +280,14 @@ int gemm_bf16_w8(const GemmArgs& p, int epi, int act, hipStream_t st) {
     if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE, 3>(p, st);
     if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU, 3>(p, st);
   }
-  if (!generic && p.bias && p.resid && p.xb_out && p.stats_part && !p.fold_mr && epi == EPI_F32 && act == ACT_NONE)
+  if (!generic && p.bias && p.resid && p.xb_out && p.stats_part && !p.fold_mr && epi == EPI_F32 && act == ACT_NONE) {
+#ifdef W8_F32_SKEW      // the LayerNorm-fold producer under the K-loop as well (api.hip linear_resid_stats, CACO_LN_FOLD=1)
+    int num_cu = 0;
+    CACO_TRY_RC(prepare_launch(reinterpret_cast<const void*>(&gemm_bf16_w8s_kernel<true>), W_SMEM, &num_cu));
+    if (gemm_bf16_w8s_ok(p, num_cu / 8 * 8)) return launch_w8s<true>(p, st);
+#endif
     return launch_w8<EPI_F32, ACT_NONE, 4>(p, st);
+  }
   if (epi == EPI_BF16) {
     if (act == ACT_NONE) return launch_w8<EPI_BF16, ACT_NONE>(p, st);
     if (act == ACT_SILU) return launch_w8<EPI_BF16, ACT_SILU>(p, st);

@@ -128,7 +128,12 @@ def test_skewed_row_block_variant_budget(tmp_path_factory):
     s_waitcnt vmcnt(12) of the NEXT event - nothing may read, copy or spill them in between."""
     text = _assembly("gemm_w8.hip", tmp_path_factory, ["-DW8_F32_SKEW"])
     kernels, meta = _kernels(text)
-    name = _find(meta, "gemm_bf16_w8s_kernel")
+    # two instantiations: <false> the plain fp32 + residual form, <true> the LayerNorm-fold producer (bf16 copy + row statistics)
+    for fold, tag in ((False, "gemm_bf16_w8s_kernelILb0E"), (True, "gemm_bf16_w8s_kernelILb1E")):
+        _skew_kernel_checks(text, kernels, meta, _find(meta, tag), fold)
+
+
+def _skew_kernel_checks(text, kernels, meta, name, fold):
     assert meta[name]["scratch"] == 0 and meta[name]["vgpr"] <= 256 and meta[name]["occ"] == 2, meta[name]
     # the other kernels of the translation unit are the default build's (the variant only adds one)
     assert all(m["scratch"] == 0 for k, m in meta.items() if "gemm_bf16_w8_kernel" in k)
@@ -144,9 +149,11 @@ def test_skewed_row_block_variant_budget(tmp_path_factory):
     stores = [i for i in flat if i.startswith("buffer_store_dwordx4")]
     burst_loads = [i for i in flat if i.startswith("buffer_load_dwordx4") and "sc0 sc1" in i and "lds" not in i]
     assert len(rd_loads) == 36 and len(stores) == 36 + 28 and len(burst_loads) == 28, (len(rd_loads), len(stores), len(burst_loads))
+    # fold producer: 4 bf16 row pieces + 1 statistics pair per completed block (9 event sites + 7 blocks of the burst), never masked
+    assert sum(1 for i in flat if i.startswith("buffer_store_dwordx2")) == (5 * (9 + 7) if fold else 0)
     # waits: vmcnt(0) only before the loop and at the very end; the events' and the K-tile barriers' counted waits are 12 / 4
     waits = Counter(re.search(r"vmcnt\((\d+)\)", i).group(1) for i in flat if i.startswith("s_waitcnt") and "vmcnt" in i)
-    assert waits["12"] >= 17 and waits["4"] >= 8, waits
+    assert waits["17" if fold else "12"] >= 17 and waits["4"] >= 8, waits
     loop_blocks = [b for b in blocks if any("v_mfma" in i for i in b)]
     assert not any("vmcnt(0)" in i for b in loop_blocks for i in b), "a full drain inside the K-loop"
     # the residual registers: the same 16 at every event site ...
@@ -189,7 +196,7 @@ def test_skewed_row_block_variant_budget(tmp_path_factory):
     def transfer(lab, state, check):
         state = set(state)
         for i in body[lab]:
-            if i.startswith("s_waitcnt") and ("vmcnt(0)" in i or ("vmcnt(12)" in i and "lgkmcnt" not in i)):
+            if i.startswith("s_waitcnt") and ("vmcnt(0)" in i or ((f"vmcnt({17 if fold else 12})") in i and "lgkmcnt" not in i)):
                 state = set()
                 continue
             if i.startswith("buffer_load_dwordx4") and " nt" in i and "lds" not in i:

@@ -4,7 +4,7 @@
     python tools/ab_variants.py [--reps 5] [--steps 10] [--out gpurun_out/r4_v0/ab_variants.json] default classic f32direct ...
 
 Every name is `default` (cacophony_amd/libcaco_hip.so) or a library under cacophony_amd/_variants/libcaco_hip_<name>.so
-(tools/build_variants.sh).  All of them are dlopen'ed side by side - each has its own process-global state, they share one HIP
+(tools/build_variants.sh); `<name>+fold` runs that library's model in the LayerNorm-folded form (caco_model_set_ln_fold).  All of them are dlopen'ed side by side - each has its own process-global state, they share one HIP
 runtime - and one model per library is created from the SAME seeded state dict; the bench step (bench.make_step) of each is timed
 in a rotated order, `steps` steps per visit, so that every variant sees the same box, clock / thermal state and neighbours.
 Per-stage times come from each library's own HIP-event recorder.  Verdict as in tools/ab_switches.py: WIN when the variant beats the
@@ -67,10 +67,11 @@ def main():
 
     libs, models, steps, outs = {}, {}, {}, {}
     for name in names:
-        if name == "default":
+        base, _, opt = name.partition("+")          # "skew+fold": library `skew`, its model in the LayerNorm-folded form
+        if base == "default":
             lib = default_lib
         else:
-            path = args.lib_pattern.format(name=name)
+            path = args.lib_pattern.format(name=base)
             if not os.path.exists(path):
                 print(f"skip {name}: {path} not built (tools/build_variants.sh)")
                 continue
@@ -90,6 +91,10 @@ def main():
             models[name] = CACO(a, t, cc, device=device).load_state_dict(state)
         finally:
             _lib._lib = saved
+        if opt == "fold":
+            assert int(lib.caco_model_set_ln_fold(models[name]._handle, 1)) == 1
+        elif opt:
+            raise SystemExit(f"unknown option in variant name {name!r} (only +fold)")
         libs[name] = lib
         outs[name] = torch.empty(args.batch, args.batch, dtype=torch.float32, device=device)
         steps[name] = bench.make_step(models[name], wav, ids, mask, outs[name], similarity, gather_packed)

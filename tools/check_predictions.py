@@ -26,6 +26,8 @@ STEP = [
     ("classic", +0.2, +1.1, "round 4: the default (peeled / packed) beats `classic` by 0.2 .. 1.1 ms per step"),
     ("skew", -2.2, -1.8, "round 5: skew (circular) beats the default by 1.8 .. 2.2 ms per step (if the power cap returns cycles as time)"),
     ("skew_lin", -1.3, -1.0, "round 5: skew_lin beats the default by 1.0 .. 1.3 ms per step"),
+    ("default+fold", -0.3, +0.8, "round 2 measured: the LayerNorm-folded stack on the serialized epilogues is a wash (-2.2 ms of LN passes, +2.7 ms of epilogues)"),
+    ("skew+fold", -3.7, -2.3, "round 5: with the fold producers under the K-loop the folded stack wins another 0.5 .. 1.5 ms over skew alone"),
 ]
 
 

@@ -72,7 +72,7 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>
       echo "== $v (rep $rep)"; CACO_ALLOW_VARIANT_LIB=1 timeout 120 python tools/gemm_bench.py --only out,fc2 --iters 20
     done; done; unset CACO_LIB_PATH; } > "$OUT/gemm_f32r_isolated.txt" 2>&1; cat "$OUT/gemm_f32r_isolated.txt"
   # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated order)
-  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default skew skew_lin skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
+  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default default+fold skew skew+fold skew_lin skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
   python tools/check_predictions.py "$OUT/ab_variants.json" "$OUT/bench.json" 2>&1 | tee "$OUT/predictions_vs_measured.txt"      # stated before, checked after
   (CACO_PINGPONG=1 timeout 600 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_variants_pingpong.json" default st_plain ln_nt a_nt 2>&1 | tail -20) | tee "$OUT/ab_variants_pingpong.txt"     # ping-pong x store policy
 fi

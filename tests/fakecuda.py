@@ -123,7 +123,8 @@ def install():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(repo, "tools", "wavesim"))
     import build_sim
-    path = build_sim.build(verbose=False)                     # rebuilds tools/wavesim/libcaco_sim.so if it is stale
+    # CACO_SIM_LIB: a variant build of the simulator library (e.g. tools/wavesim/libcaco_sim_skew.so) under the GPU suite's bodies
+    path = os.environ.get("CACO_SIM_LIB") or build_sim.build(verbose=False)      # rebuilds tools/wavesim/libcaco_sim.so if it is stale
     os.environ["CACO_LIB_PATH"] = path
     os.environ["CACO_ALLOW_VARIANT_LIB"] = "1"          # _lib.load() refuses any library but the product's without it
     if "cacophony_amd._lib" in sys.modules:

@@ -100,15 +100,38 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
     from cacophony_amd.build import EXTRA_FLAGS as product_extra          # -D flags a flipped variant added to the product build
     headers = headers + [os.path.join(REPO, "cacophony_amd", "build.py")]
 
+    # A variant's -D macros usually touch one translation unit: a unit whose source (and the csrc headers / .inc pieces, which any
+    # unit may include) never names one of them compiles to the same object as in the untagged build, so that object is shared.
+    macros = [re.sub(r"^-D", "", d).split("=")[0] for d in defines if d.startswith("-D")]
+    san_tag = (".asan" if asan else "") + (".tsan" if tsan else "") + (".ubsan" if ubsan else "")
+
+    def closure_text(path, seen=None):
+        """The unit's source plus every csrc file it includes with quotes, transitively (conditional includes count too)."""
+        seen = set() if seen is None else seen
+        if path in seen or not os.path.exists(path):
+            return ""
+        seen.add(path)
+        text = open(path).read()
+        for inc in re.findall(r'#include\s+"([^"]+)"', text):
+            text += closure_text(os.path.join(CSRC, inc), seen)
+        return text
+
+    def untouched(path, base):
+        if not macros or base in replace or not base.endswith(".hip"):
+            return False
+        text = closure_text(path)
+        return not any(re.search(rf"\b{re.escape(m)}\b", text) for m in macros)
+
     def one(src):
         path = src if os.path.isabs(src) else os.path.join(CSRC, src)
         base = os.path.basename(path)
         if base in replace:
             path = replace[base]
-        obj = os.path.join(GEN, base.replace(".hip", tag + ".o").replace(".cpp", tag + ".o"))
+        obj_tag = san_tag if untouched(path, base) else tag
+        obj = os.path.join(GEN, base.replace(".hip", obj_tag + ".o").replace(".cpp", obj_tag + ".o"))
         if not force and _newer(obj, [path] + headers):
             return obj
-        gen = os.path.join(GEN, base.replace(".hip", tag + ".cpp"))
+        gen = os.path.join(GEN, base.replace(".hip", obj_tag + ".cpp"))
         if base.endswith(".hip"):
             with open(path) as f:
                 t = translate(f.read())
@@ -117,7 +140,8 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         else:
             gen = path
         san = ["-fsanitize=thread"] if (tsan and base.endswith(".hip")) else []
-        cmd = [CXX, *flags, *[f for f in product_extra.get(base, []) if f.startswith("-D")], *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
+        use_flags = [f for f in flags if f not in defines] if obj_tag != tag else flags
+        cmd = [CXX, *use_flags, *[f for f in product_extra.get(base, []) if f.startswith("-D")], *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{base}:\n{r.stdout}\n{r.stderr}")

@@ -4,7 +4,7 @@
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh ab'       bash tools/gpurun_variants.sh --timeout 2400 -- 'bash tools/gpu_session.sh variants'
 #   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh pmc'      bash tools/gpurun_variants.sh --timeout 1500 -- 'bash tools/gpu_session.sh bisect'
 # 1. truth: hardware record of the DEFAULT build: pytest -m gpu (default path), smoke, bench, rocprofv3 kernel stats, then the
-#    experimental cases  -> gpurun_out/r5_v0/   (copy to profiles/r5_v0/)
+#    experimental cases  -> gpurun_out/r6_v0/   (copy to profiles/r6_v0/)
 # 2. ab: every run-time switch against the default, interleaved in one process (tools/ab_switches.py: flip / delete verdicts),
 #    rocprofv3 kernel stats with the fusions on, GEMM kernels per shape (w8 / w4q / w4h / x / 128), fc1 inside chains
 # 3. variants: compile-time A/B libraries (tools/build_variants.sh; they travel only with tools/gpurun_variants.sh), the skew and
@@ -13,7 +13,7 @@
 # Every part is wrapped in its own timeout so that a hang cannot eat the call.
 set -u
 PART=${1:-all}
-OUT=${OUT:-gpurun_out/r5_v0}
+OUT=${OUT:-gpurun_out/r6_v0}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
@@ -25,8 +25,8 @@ tail -3 "$OUT/pytest_gpu.txt"
 cat "$OUT/smoke.txt"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 head -c 600 "$OUT/bench.json"; echo
-bash tools/profile_bench.sh r5_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
-cp gpurun_out/prof_r5_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
+bash tools/profile_bench.sh r6_default --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_default.txt" 2>&1
+cp gpurun_out/prof_r6_default/kernel_stats_summary.csv "$OUT/kernel_stats_default.csv" 2>/dev/null
 # the experimental cases last: the product's record (pytest, smoke, bench, kernel stats) must exist before anything optional runs
 (CACO_RUN_EXPERIMENTAL=1 timeout 900 python -m pytest tests -m "gpu and experimental" -q 2>&1 | tail -40) > "$OUT/pytest_gpu_experimental.txt"   # never-default kernels, opt-in switches (no -x)
 tail -3 "$OUT/pytest_gpu_experimental.txt"
@@ -34,8 +34,8 @@ fi
 if want ab; then
 # every run-time switch against the default, interleaved inside ONE process (caco_set_switch), with the flip / delete verdict
 (timeout 900 python tools/ab_switches.py --reps 5 --steps 10 --out "$OUT/ab_switches.json" 2>&1 | tail -40) | tee "$OUT/ab_switches.txt"
-CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r5_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
-cp gpurun_out/prof_r5_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
+CACO_ATTN_SMALL=1 CACO_POS_FUSE=1 CACO_POOL_FUSE=1 bash tools/profile_bench.sh r6_switches --steps 10 --warmup 3 --no-extra-configs > "$OUT/prof_switches.txt" 2>&1
+cp gpurun_out/prof_r6_switches/kernel_stats_summary.csv "$OUT/kernel_stats_switches.csv" 2>/dev/null
 { for t in 8256 4256 8256 4256; do echo "tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only qkv,out,fc1,fc2,t_fc1,t_fc2 --iters 20; done;
   for t in 128 2256 8256 4256 4128; do echo "text shapes, tile $t"; timeout 120 python tools/gemm_bench.py --tile $t --only t_qkv,t_out,t_fc1,t_fc2 --iters 50; done; } > "$OUT/gemm_w8_vs_w4q.txt" 2>&1; cat "$OUT/gemm_w8_vs_w4q.txt"
 (timeout 300 python tools/gemm_chain_bench.py 2>&1 | tail -8) > "$OUT/gemm_chain.txt"; cat "$OUT/gemm_chain.txt"
@@ -78,15 +78,15 @@ if want variants && ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>
 fi
 # PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)
 if want pmc; then
-  bash tools/pmc_run.sh r3_pmc_fc1 gemm_bf16_w8 -- python tools/gemm_bench.py --iters 3 --only fc1 > /dev/null 2>&1
-  bash tools/pmc_run.sh r3_pmc_attn attention_kernel -- python tools/attn_bench.py > /dev/null 2>&1
-  bash tools/pmc_run.sh r3_pmc_mel mel_kernel -- python tools/mel_bench.py > /dev/null 2>&1
-  for k in fc1 attn mel; do for f in sq1 sq2 sq3 tcc1 tcc2; do cat gpurun_out/r3_pmc_$k/$f.csv gpurun_out/r3_pmc_$k/$f.dur > "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
+  bash tools/pmc_run.sh r6_pmc_fc1 gemm_bf16_w8 -- python tools/gemm_bench.py --iters 3 --only fc1 > /dev/null 2>&1
+  bash tools/pmc_run.sh r6_pmc_attn attention_kernel -- python tools/attn_bench.py > /dev/null 2>&1
+  bash tools/pmc_run.sh r6_pmc_mel mel_kernel -- python tools/mel_bench.py > /dev/null 2>&1
+  for k in fc1 attn mel; do for f in sq1 sq2 sq3 tcc1 tcc2; do cat gpurun_out/r6_pmc_$k/$f.csv gpurun_out/r6_pmc_$k/$f.dur > "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
   # fabric reads of every kernel of the step, default order vs ping-pong traversal (does the Infinity Cache keep a producer's tail?)
-  bash tools/pmc_run.sh r3_pmc_step_ng0 kernel -- env CACO_W_NGROUP=0 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
-  bash tools/pmc_run.sh r3_pmc_step_pp kernel -- env CACO_PINGPONG=1 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
-  for k in step_ng0 step_pp; do for f in tcc1 tcc2; do cp gpurun_out/r3_pmc_$k/$f.csv "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
-  bash tools/pmc_hbm.sh r3_hbm fc1 256 > /dev/null 2>&1; cp gpurun_out/r3_hbm/hbm_traffic.json "$OUT/" 2>/dev/null
+  bash tools/pmc_run.sh r6_pmc_step_ng0 kernel -- env CACO_W_NGROUP=0 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  bash tools/pmc_run.sh r6_pmc_step_pp kernel -- env CACO_PINGPONG=1 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  for k in step_ng0 step_pp; do for f in tcc1 tcc2; do cp gpurun_out/r6_pmc_$k/$f.csv "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
+  bash tools/pmc_hbm.sh r6_hbm fc1 256 > /dev/null 2>&1; cp gpurun_out/r6_hbm/hbm_traffic.json "$OUT/" 2>/dev/null
   ls "$OUT"
 fi
 echo "session done"

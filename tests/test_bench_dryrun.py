@@ -1,6 +1,6 @@
 """bench.py's multi-process control flow, executed before any 8-GPU driver run: warm-up, the (synchronize, barrier,
 synchronize) fences, the timed loop, the MAX all-reduce of the ranks' wall times, rank 0's single JSON line and the
-teardown order - on the gloo backend at world size 2 (CACO_BENCH_DRYRUN=1: no GPU, no library).
+teardown order - on the gloo backend at world size 2 and at the target's world size 8 (CACO_BENCH_DRYRUN=1: no GPU, no library).
 The per-rank step is bench.make_step itself - encode_pairs(packed) -> dist.gather_packed -> similarity into this rank's
 row block - with CPU stand-ins for the towers and the similarity kernel only: the exchange, the strided views and the row
 block placement are the real ones, and the row block is checked against an independent all-gather."""
@@ -40,6 +40,20 @@ def test_bench_control_flow_two_ranks_gloo():
     assert abs(out["value"] - 2 * 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3
     assert out["data"].startswith("none")      # a dry run can never be mistaken for a measurement
     assert out["dryrun_row_block_max_err"] < 1e-6      # the step closure left rank 0's [256, 512] row block in place
+
+
+def test_bench_control_flow_eight_ranks_gloo():
+    """The driver's own N = 8 command line (SCALE_rNN.json) with gloo in RCCL's place: eight ranks of unequal speed, one
+    packed all-gather per step, rank 0's [256, 2048] row block in rank order, ONE JSON line, clean teardown."""
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"],
+               CACO_BENCH_CHECK_SIZES="1")
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2048 and out["config"]["parallelism"] == "dp8"
+    assert out["ms_per_step"] >= 15.9          # the slowest rank (rank 7 sleeps 16 ms per step) sets the time
+    assert abs(out["value"] - 8 * 256 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-3      # whole-job pairs/s
+    assert out["data"].startswith("none") and out["cpu_baseline"] is None
+    assert out["dryrun_row_block_max_err"] < 1e-6
 
 
 def test_bench_step_closure_refuses_unequal_shards_on_every_rank():

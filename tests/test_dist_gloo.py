@@ -60,6 +60,52 @@ def test_two_rank_gather_and_row_blocks(tmp_path):
     assert full.shape == (12, 12)
 
 
+def _worker8(rank, world, port, n_global):
+    """World size 8 (the target node): shard_range's spans -> packed banks -> ONE gather.  2048 rows divide (256 each, the
+    configs[3] shape); 2049 do not - rank 0 gets 257 rows - and check_sizes must refuse that on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        a_all = torch.randn(n_global, 16, generator=g)
+        t_all = torch.randn(n_global, 16, generator=g)
+        lo, hi = cdist.shard_range(n_global, rank, world)
+        bank = torch.stack([a_all[lo:hi], t_all[lo:hi]], 1).contiguous()
+        if n_global % world:
+            assert hi - lo == n_global // world + (1 if rank < n_global % world else 0)
+            try:
+                cdist.gather_packed(bank, check_sizes=True)
+                raised = False
+            except ValueError as e:
+                raised = "pad the shards to one size" in str(e)
+            assert raised, f"rank {rank}: {hi - lo} rows of {n_global} over {world} ranks were not refused"
+        else:
+            allb = cdist.gather_packed(bank, check_sizes=True)
+            assert allb.shape == (n_global, 2, 16) and torch.equal(allb[:, 0], a_all) and torch.equal(allb[:, 1], t_all)
+            block = cdist.sharded_similarity(a_all[lo:hi], t_all[lo:hi], similarity_fn=lambda a, t, s: s * a @ t.T)
+            assert block.shape == (n_global // world, n_global)
+            assert torch.allclose(block, (a_all @ t_all.T)[lo:hi], atol=1e-5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gather_2048_rows():
+    mp.spawn(_worker8, args=(8, _free_port(), 2048), nprocs=8, join=True)
+
+
+def test_eight_rank_remainder_shards_are_refused():
+    """2049 rows over 8 ranks: shard_range's remainder branch gives rank 0 one row more; every rank must raise."""
+    mp.spawn(_worker8, args=(8, _free_port(), 2049), nprocs=8, join=True)
+
+
+def test_shard_range_remainder_goes_to_the_first_ranks():
+    spans = [cdist.shard_range(2049, r, 8) for r in range(8)]
+    assert spans[0] == (0, 257) and spans[1] == (257, 513) and spans[-1] == (1793, 2049)
+    assert [hi - lo for lo, hi in spans] == [257] + [256] * 7
+    spans = [cdist.shard_range(2055, r, 8) for r in range(8)]
+    assert [hi - lo for lo, hi in spans] == [257] * 7 + [256] and spans[-1][1] == 2055
+
+
 def test_shard_range_covers_everything():
     for n, w in ((2048, 8), (10, 3), (7, 8), (256, 1)):
         spans = [cdist.shard_range(n, r, w) for r in range(w)]

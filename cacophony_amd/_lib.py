@@ -147,7 +147,11 @@ class switch:
         return self
 
     def __exit__(self, *exc):
-        load().caco_set_switch(self.name, self.prev)
+        # a restore the library refuses would leave this block's value in force for everything that runs later: raise, unless an
+        # exception is already on its way out of the block
+        status = load().caco_set_switch(self.name, self.prev)
+        if exc[0] is None:
+            check(status, f"caco_set_switch restore {self.name.decode()}={self.prev}")
         return False
 
 

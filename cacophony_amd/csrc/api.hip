@@ -46,13 +46,28 @@ static SwitchSlot g_switches[SW_COUNT] = {
     {"CACO_ATTN_SMALL", 0, {INT_MIN}},   {"CACO_ATTN_ROWS", 64, {INT_MIN}}, {"CACO_W_NGROUP", -1, {INT_MIN}},
     {"CACO_W8_MIN_TILES", 128, {INT_MIN}}, {"CACO_W4H_MAX_TILES", 0, {INT_MIN}},
 };
+// per-switch ranges, one rule for both ways in (environment, caco_set_switch): INT_MIN is the "environment not read yet" sentinel and
+// must never be stored (it would re-arm the getenv), and an out-of-range value would go straight to a launch path
+static bool switch_value_ok(Switch s, int value) {
+  if (value == INT_MIN) return false;
+  switch (s) {
+    case SW_PINGPONG: case SW_POS_FUSE: case SW_POOL_FUSE: case SW_ATTN_SMALL: return value == 0 || value == 1;
+    case SW_ATTN_ROWS: return value == 32 || value == 64;
+    case SW_W_NGROUP: return value >= -1 && value <= 4096;
+    case SW_W8_MIN_TILES: case SW_W4H_MAX_TILES: return value >= 0;
+    default: return true;
+  }
+}
 int sw(Switch s) {
   SwitchSlot& slot = g_switches[s];
   int v = slot.value.load(std::memory_order_relaxed);
   if (v == INT_MIN) {                      // first use in this process: the environment's value, or the default
     const char* e = getenv(slot.name);
     v = e && *e ? atoi(e) : slot.def;
-    if (v == INT_MIN) v = slot.def;
+    if (!switch_value_ok(s, v)) {          // same ranges as caco_set_switch: a bad environment value never reaches a launch path
+      fprintf(stderr, "[cacophony_amd] %s=%s is out of range: using the default %d\n", slot.name, e ? e : "", slot.def);
+      v = slot.def;
+    }
     int expect = INT_MIN;
     if (!slot.value.compare_exchange_strong(expect, v, std::memory_order_relaxed)) v = expect;
   }
@@ -766,17 +781,7 @@ int caco_set_switch(const char* name, int32_t value) {
   CACO_REQUIRE(name, "caco_set_switch: null name");
   for (int i = 0; i < SW_COUNT; ++i)
     if (!strcmp(name, g_switches[i].name)) {
-      // per-switch ranges: INT32_MIN is the "environment not read yet" sentinel and must never be stored (it would re-arm the
-      // getenv), and an out-of-range value would go straight to a launch path
-      bool ok = value != INT32_MIN;
-      switch ((Switch)i) {
-        case SW_PINGPONG: case SW_POS_FUSE: case SW_POOL_FUSE: case SW_ATTN_SMALL: ok = ok && (value == 0 || value == 1); break;
-        case SW_ATTN_ROWS: ok = ok && (value == 32 || value == 64); break;
-        case SW_W_NGROUP: ok = ok && value >= -1 && value <= 4096; break;
-        case SW_W8_MIN_TILES: case SW_W4H_MAX_TILES: ok = ok && value >= 0; break;
-        default: break;
-      }
-      CACO_REQUIRE(ok, "caco_set_switch: value %d out of range for %s", (int)value, name);
+      CACO_REQUIRE(switch_value_ok((Switch)i, value), "caco_set_switch: value %d out of range for %s", (int)value, name);
       sw((Switch)i);                               // settle the environment's initial value first, so that it cannot overwrite this one
       g_switches[i].value.store(value, std::memory_order_relaxed);
       return CACO_OK;

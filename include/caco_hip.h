@@ -204,8 +204,9 @@ int32_t caco_set_gemm_tile(int32_t tile);
  * CACO_W4H_MAX_TILES).  A switch takes its initial value from the environment variable of the same name ONCE, at its first
  * use in the process; afterwards only caco_set_switch changes it (no launch path reads the environment).  Unknown name:
  * CACO_ERR_INVALID resp. INT32_MIN.  A value outside the switch's range (0 / 1 for the on-off switches, 32 / 64 for
- * CACO_ATTN_ROWS, >= -1 for CACO_W_NGROUP, >= 0 for the tile thresholds; never INT32_MIN) is CACO_ERR_INVALID and changes
- * nothing.  The reference has no counterpart: its knobs are Python arguments. */
+ * CACO_ATTN_ROWS, -1 .. 4096 for CACO_W_NGROUP, >= 0 for the tile thresholds; never INT32_MIN) is CACO_ERR_INVALID and changes
+ * nothing; the same ranges apply to the environment's initial value (out of range: the default, with a line on stderr).
+ * The reference has no counterpart: its knobs are Python arguments. */
 int caco_set_switch(const char* name, int32_t value);
 int32_t caco_get_switch(const char* name);
 /* Tuning knob: LayerNorm folding in the audio stack (the LayerNorm passes disappear into the neighbouring GEMM

@@ -60,7 +60,8 @@ def sync_switches(lib=None) -> None:
     lib = lib or load()
     for name in SWITCHES:
         v = os.environ.get(name)
-        lib.caco_set_switch(name.encode(), int(v) if v not in (None, "") else _SWITCH_DEFAULTS.get(name, 0))
+        value = int(v) if v not in (None, "") else _SWITCH_DEFAULTS.get(name, 0)
+        check(lib.caco_set_switch(name.encode(), value), f"caco_set_switch {name}={value}", lib)      # a refused value must not pass silently
 
 
 def check(status: int, what: str = "", lib=None) -> None:

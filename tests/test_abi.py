@@ -142,6 +142,24 @@ def test_run_time_switches_read_their_environment_once_then_only_the_api(tmp_pat
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "[1, 2, 64, 128, 0] [1, 0] 0"
+    # the environment goes through the same per-switch ranges as caco_set_switch: an out-of-range initial value is replaced by the
+    # default (with a line on stderr) instead of reaching a launch path, and the context manager can then restore what it found
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "from cacophony_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "g = lambda n: lib.caco_get_switch(n.encode())\n"
+        "first = [g(n) for n in ('CACO_PINGPONG', 'CACO_ATTN_ROWS', 'CACO_W8_MIN_TILES', 'CACO_W_NGROUP', 'CACO_POS_FUSE')]\n"
+        "with _lib.switch('CACO_PINGPONG', 1):\n"
+        "    inside = g('CACO_PINGPONG')\n"
+        "print(first, inside, g('CACO_PINGPONG'))\n" % root)
+    env = dict(os.environ, CACO_PINGPONG="2", CACO_ATTN_ROWS="48", CACO_W8_MIN_TILES="-5", CACO_W_NGROUP="5000", CACO_POS_FUSE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "[0, 64, 128, -1, 1] 1 0"
+    for name in ("CACO_PINGPONG=2", "CACO_ATTN_ROWS=48", "CACO_W8_MIN_TILES=-5", "CACO_W_NGROUP=5000"):
+        assert f"{name} is out of range" in out.stderr, out.stderr[-1000:]
+    assert "CACO_POS_FUSE" not in out.stderr
 
 
 def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):

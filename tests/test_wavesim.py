@@ -126,7 +126,7 @@ def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
     own K-loop.  Against torch fp32 at fp32 rounding (sum order differs from the other kernels: bias first, K-tiles rotated per
     row block), with guard rows around the output, in place and with a separate residual; and the DEFAULT build on the same
     case must differ from it in bits (otherwise the launch fell back to gemm_bf16_w8 and the case tests nothing)."""
-    out, ref, ref64 = _skew_case(skew_sim, M, N, K, 40)
+    out, ref, ref64 = _skew_case(skew_sim, M, N, K, 40, inplace=inplace)
     err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
     err32 = ((ref.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
     # measured against float64, as a fraction of 1 + |ref|: 1.8e-6 .. 2.4e-6 for K <= 1024 and 4.2e-6 at K = 3072; gemm_bf16_w8 on
@@ -136,7 +136,7 @@ def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
     d32 = ((out - ref).abs() / (ref.abs() + 1.0)).max().item()      # two fp32 roundings apart: up to the sum of both errors
     print(f"[skew] M {M} N {N} K {K}: vs float64 {err:.2e} (torch fp32 {err32:.2e}), vs torch fp32 {d32:.2e}")
     assert d32 <= (3.5e-6 if K <= 1024 else 7e-6)
-    base, _, _ = _skew_case(sim, M, N, K, 40)
+    base, _, _ = _skew_case(sim, M, N, K, 40, inplace=inplace)
     assert not torch.equal(base, out), "identical bits: the skewed kernel did not run"
     assert (base - out).abs().max().item() < 1e-4
 
@@ -153,11 +153,11 @@ def test_gemm_skewed_linear_panel_list(sim):
     """The linear form of the same kernel (-DW8_SKEW_LINEAR, variant `skew_lin`: first-period blocks idle, a tail period at the
     end) - the other arm of the A/B against the circular panel list of `skew`."""
     lin = _variant_sim("skew_lin", ["-DW8_F32_SKEW", "-DW8_SKEW_LINEAR"])
-    for M, N, K in ((2000, 768, 768), (2304, 512, 3072), (1800, 768, 640)):
-        out, ref, ref64 = _skew_case(lin, M, N, K, 40)
+    for M, N, K, inplace in ((2000, 768, 768, True), (2304, 512, 3072, True), (1800, 768, 640, False)):
+        out, ref, ref64 = _skew_case(lin, M, N, K, 40, inplace=inplace)
         err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
         assert err <= (3e-6 if K <= 1024 else 7e-6), (M, N, K, err)
-        base, _, _ = _skew_case(sim, M, N, K, 40)
+        base, _, _ = _skew_case(sim, M, N, K, 40, inplace=inplace)
         assert not torch.equal(base, out)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of compile-time variant libraries inside ONE process (GPU box).
 
-    python tools/ab_variants.py [--reps 5] [--steps 10] [--out gpurun_out/r4_v0/ab_variants.json] default classic f32direct ...
+    python tools/ab_variants.py [--reps 5] [--steps 10] [--out gpurun_out/r6_v0/ab_variants.json] default skew classic ...
 
 Every name is `default` (cacophony_amd/libcaco_hip.so) or a library under cacophony_amd/_variants/libcaco_hip_<name>.so
 (tools/build_variants.sh); `<name>+fold` runs that library's model in the LayerNorm-folded form (caco_model_set_ln_fold).  All of them are dlopen'ed side by side - each has its own process-global state, they share one HIP

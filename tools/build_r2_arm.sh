@@ -4,7 +4,8 @@
 # exported with `git archive` into a temp directory and built there with THAT commit's own build.py ->
 #   cacophony_amd/_variants/libcaco_hip_r2.so        (git-ignored; travels with gpurun like the other variants)
 # Nothing of it enters the product tree.  The library predates caco_set_switch / caco_get_switch: cacophony_amd/_lib.py binds
-# the symbols a variant library lacks to a stub that raises (only under CACO_ALLOW_VARIANT_LIB=1).
+# the two switch entry points a variant library lacks to stubs that answer CACO_ERR_INVALID / INT32_MIN ("unknown switch"; only under
+# CACO_ALLOW_VARIANT_LIB=1, never for the product library); tools/ab_variants.py leaves them unbound.
 # Use: CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_r2.so python -m pytest tests/test_gpu_ops.py -m gpu -k "gemm or ragged"
 #      python tools/ab_variants.py default r2 classic libm_erf r2addr
 set -e

@@ -3,7 +3,7 @@
 against what a GPU session measured.  Reads tools/ab_variants.py's JSON (per-stage times of every library in one process) and,
 optionally, the truth session's bench line; prints one row per prediction with HELD / MISSED and the measured per-launch time.
 
-    python tools/check_predictions.py gpurun_out/r5_v0/ab_variants.json [gpurun_out/r5_v0/bench.json]
+    python tools/check_predictions.py gpurun_out/r6_v0/ab_variants.json [gpurun_out/r6_v0/bench.json]
 
 No GPU needed (it only reads the records); exits 0 whatever the outcome - it is a report, not a test."""
 import json
@@ -18,8 +18,8 @@ PREDICTIONS = [
     ("skew", "audio.gemm_fc2", "round 5: epilogue under the K-loop, circular panel list, 0.54 -> <= 0.41 ms", 0.0, 0.41, "csrc/gemm_w8_skew.inc"),
     ("skew_lin", "audio.gemm_out", "round 5: linear panel list (8 extra K-tiles per launch), 0.23 -> <= 0.21 ms", 0.0, 0.21, "csrc/gemm_w8_skew.inc"),
     ("skew_lin", "audio.gemm_fc2", "round 5: linear panel list (43 extra K-tiles per launch), 0.54 -> <= 0.46 ms", 0.0, 0.46, "csrc/gemm_w8_skew.inc"),
-    ("skew_d2", "audio.gemm_fc2", "round 5: events bunched (D = 2): within 0.02 ms of skew", 0.0, 0.43, "tools/build_variants.sh"),
     ("attn_lean", "audio.attention", "round 5: no spill, epilogue on register pairs, 0.264 -> 0.255-0.262 ms", 0.0, 0.262, "tools/build_variants.sh"),
+    ("attn_lean_k2", "audio.attention", "round 5: attn_lean + K fragment reads pinned 2 steps ahead, 0.264 -> 0.245-0.262 ms", 0.0, 0.262, "tools/build_variants.sh"),
 ]
 # step-level predictions: (variant, delta vs default in ms: lower, upper, text)
 STEP = [
@@ -28,6 +28,8 @@ STEP = [
     ("skew_lin", -1.3, -1.0, "round 5: skew_lin beats the default by 1.0 .. 1.3 ms per step"),
     ("default+fold", -0.3, +0.8, "round 2 measured: the LayerNorm-folded stack on the serialized epilogues is a wash (-2.2 ms of LN passes, +2.7 ms of epilogues)"),
     ("skew+fold", -3.7, -2.3, "round 5: with the fold producers under the K-loop the folded stack wins another 0.5 .. 1.5 ms over skew alone"),
+    ("wb", -0.3, +0.3, "round 6: default cache policy on every epilogue store / residual load of the persistent GEMM: inside the box's spread"),
+    ("hints", -0.3, +0.3, "round 6: nt on the GEMM operands, attention and LayerNorm output stores: inside the box's spread (W with nt may lose)"),
 ]
 
 
@@ -57,7 +59,7 @@ def main():
         b = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
         r = b.get("roofline") or {}
         print(f"\nbench line: {b.get('ms_per_step')} ms/step, {b.get('value')} {b.get('unit')}; fc1 {r.get('avg_launch_ms')} ms = frac {r.get('frac')} "
-              f"(targets of the round-4 verdict: step <= 27.0 ms, fc1 frac >= 0.45); library {b.get('config', {}).get('lib_path')}")
+              f"(targets of the round-5 verdict: step <= 26.0 ms, fc1 frac >= 0.45); library {b.get('config', {}).get('lib_path')}")
     return 0
 
 

@@ -53,28 +53,30 @@ if [ "$PART" = bisect ]; then
   done
   (timeout 900 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_arms.json" default r2 classic libm_erf r2addr 2>&1 | tail -30) | tee "$OUT/ab_arms.txt"
 fi
-# compile-time variants prepared by tools/build_variants.sh (cacophony_amd/_variants/, they travel with the snapshot)
-if want variants && ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>&1; then
-  # a variant library under the product's own op tests (CACO_ALLOW_VARIANT_LIB: the suite otherwise refuses any library but the product's)
-  (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_f32direct.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or guard" 2>&1 | tail -3) > "$OUT/pytest_f32direct.txt"
-  cat "$OUT/pytest_f32direct.txt"
-  # round 5: the skewed-row-block fp32 epilogue under the product's own GEMM cases (the chip-filling fp32 + residual shapes of
+# compile-time variants prepared by tools/build_variants.sh (cacophony_amd/_variants/; they travel only with tools/gpurun_variants.sh)
+if want variants; then
+if ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>&1; then
+  # parity first: the skewed-row-block fp32 epilogue under the product's own GEMM cases (the chip-filling fp32 + residual shapes of
   # test_gemm_persistent_multi_tile_pipeline reach it; everything else falls back to gemm_bf16_w8) and the model goldens
+  # (CACO_ALLOW_VARIANT_LIB: the suite otherwise refuses any library but the product's)
   for v in skew skew_lin; do
     (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_$v.so timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -q -m "gpu and not experimental" -k "gemm or golden or chip_filling or full_batch" 2>&1 | tail -3) > "$OUT/pytest_$v.txt"
     echo "== $v"; cat "$OUT/pytest_$v.txt"
   done
   (CACO_ALLOW_VARIANT_LIB=1 CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_attn_lean.so timeout 600 python -m pytest tests/test_gpu_ops.py -q -m "gpu and not experimental" -k "attention" 2>&1 | tail -3) > "$OUT/pytest_attn_lean.txt"
   cat "$OUT/pytest_attn_lean.txt"
-  # isolated launches of the two fp32 + residual shapes: default, skew, skew_d2 (twice, alternating: the box's own spread)
-  { for rep in 1 2; do for v in default skew skew_lin skew_d2 f32direct; do
+  # isolated launches of the two fp32 + residual shapes: default, skew, skew_lin (twice, alternating: the box's own spread)
+  { for rep in 1 2; do for v in default skew skew_lin; do
       if [ $v = default ]; then unset CACO_LIB_PATH; else export CACO_LIB_PATH=$PWD/cacophony_amd/_variants/libcaco_hip_$v.so; fi
       echo "== $v (rep $rep)"; CACO_ALLOW_VARIANT_LIB=1 timeout 120 python tools/gemm_bench.py --only out,fc2 --iters 20
     done; done; unset CACO_LIB_PATH; } > "$OUT/gemm_f32r_isolated.txt" 2>&1; cat "$OUT/gemm_f32r_isolated.txt"
-  # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated order)
-  (timeout 1500 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default default+fold skew skew+fold skew_lin skew_d2 classic bf16_wb f32_wb f32_wb_ld0 f32direct attn_lean attn_lean_k2 kpipe2 attn_nt ln_nt a_nt w_nt st_plain 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
+  # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated
+  # order); every arm has a written prediction (tools/build_variants.sh, tools/check_predictions.py): 11 arms x 5 reps
+  (timeout 1200 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default default+fold skew skew+fold skew_lin classic attn_lean attn_lean_k2 wb hints 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
   python tools/check_predictions.py "$OUT/ab_variants.json" "$OUT/bench.json" 2>&1 | tee "$OUT/predictions_vs_measured.txt"      # stated before, checked after
-  (CACO_PINGPONG=1 timeout 600 python tools/ab_variants.py --reps 3 --steps 10 --out "$OUT/ab_variants_pingpong.json" default st_plain ln_nt a_nt 2>&1 | tail -20) | tee "$OUT/ab_variants_pingpong.txt"     # ping-pong x store policy
+else
+  echo "variants skipped: libraries not present (build with tools/build_variants.sh, push with tools/gpurun_variants.sh)"
+fi
 fi
 # PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)
 if want pmc; then

@@ -1,5 +1,5 @@
 import os, subprocess, sys, re
-REPO='/root/repo'; HERE=REPO+'/tools/wavesim'
+import os; HERE=os.path.dirname(os.path.abspath(__file__)); REPO=os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 import build_sim
 lib = build_sim.build(tsan=True, defines=("-DW8_F32_SKEW",), tag="skew", verbose=False)

@@ -73,22 +73,25 @@ if ls cacophony_amd/_variants/libcaco_hip_skew.so >/dev/null 2>&1; then
   # every variant library against the default, interleaved inside ONE process (tools/ab_variants.py: one model per library, rotated
   # order); every arm has a written prediction (tools/build_variants.sh, tools/check_predictions.py): 11 arms x 5 reps
   (timeout 1200 python tools/ab_variants.py --reps 5 --steps 10 --out "$OUT/ab_variants.json" default default+fold skew skew+fold skew_lin classic attn_lean attn_lean_k2 wb hints 2>&1 | tail -50) | tee "$OUT/ab_variants.txt"
-  python tools/check_predictions.py "$OUT/ab_variants.json" "$OUT/bench.json" 2>&1 | tee "$OUT/predictions_vs_measured.txt"      # stated before, checked after
+  [ -s "$OUT/bench.json" ] && B="$OUT/bench.json" || B=""
+  [ -s "$OUT/ab_variants.json" ] && python tools/check_predictions.py "$OUT/ab_variants.json" $B 2>&1 | tee "$OUT/predictions_vs_measured.txt"      # stated before, checked after
 else
   echo "variants skipped: libraries not present (build with tools/build_variants.sh, push with tools/gpurun_variants.sh)"
 fi
 fi
 # PMC counters of the shipped kernels, one fresh session, per-dispatch min / max next to the means (round-2 verdict item 6)
 if want pmc; then
+  # first the one record bench.py quotes (roofline.traffic): fabric bytes of a fc1 launch with the DEFAULT tile order (w_ngroup -1) -
+  # copy it to profiles/r6_v0/hbm_traffic.json and commit it before the driver's end-of-round bench
+  (unset CACO_W_NGROUP; bash tools/pmc_hbm.sh r6_hbm fc1 256) > "$OUT/pmc_hbm.log" 2>&1; cp gpurun_out/r6_hbm/hbm_traffic.json "$OUT/" 2>/dev/null && cat "$OUT/hbm_traffic.json"
   bash tools/pmc_run.sh r6_pmc_fc1 gemm_bf16_w8 -- python tools/gemm_bench.py --iters 3 --only fc1 > /dev/null 2>&1
   bash tools/pmc_run.sh r6_pmc_attn attention_kernel -- python tools/attn_bench.py > /dev/null 2>&1
   bash tools/pmc_run.sh r6_pmc_mel mel_kernel -- python tools/mel_bench.py > /dev/null 2>&1
   for k in fc1 attn mel; do for f in sq1 sq2 sq3 tcc1 tcc2; do cat gpurun_out/r6_pmc_$k/$f.csv gpurun_out/r6_pmc_$k/$f.dur > "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
-  # fabric reads of every kernel of the step, default order vs ping-pong traversal (does the Infinity Cache keep a producer's tail?)
-  bash tools/pmc_run.sh r6_pmc_step_ng0 kernel -- env CACO_W_NGROUP=0 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
-  bash tools/pmc_run.sh r6_pmc_step_pp kernel -- env CACO_PINGPONG=1 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
-  for k in step_ng0 step_pp; do for f in tcc1 tcc2; do cp gpurun_out/r6_pmc_$k/$f.csv "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
-  bash tools/pmc_hbm.sh r6_hbm fc1 256 > /dev/null 2>&1; cp gpurun_out/r6_hbm/hbm_traffic.json "$OUT/" 2>/dev/null
+  # fabric reads of every kernel of the step (TCC passes only), default order vs one n-tile group (round 2's order, what profiles/r2_v3 measured)
+  PMC_PASSES="tcc1 tcc2" bash tools/pmc_run.sh r6_pmc_step kernel -- python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  PMC_PASSES="tcc1 tcc2" bash tools/pmc_run.sh r6_pmc_step_ng0 kernel -- env CACO_W_NGROUP=0 python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  for k in step step_ng0; do for f in tcc1 tcc2; do cp gpurun_out/r6_pmc_$k/$f.csv "$OUT/pmc_${k}_$f.csv" 2>/dev/null; done; done
   ls "$OUT"
 fi
 echo "session done"

@@ -27,3 +27,23 @@ def test_shell_scripts_parse():
         if f.endswith(".sh"):
             r = subprocess.run(["bash", "-n", os.path.join(tools, f)], capture_output=True, text=True)
             assert r.returncode == 0, (f, r.stderr)
+
+
+def test_hardware_history_lists_in_conftest_name_existing_gpu_cases():
+    """tests/conftest.py orders the `-m gpu` cases by hand-maintained name lists (seen on hardware in round 1 / round 2, golden
+    model cases).  A renamed test would silently drop to 'never met an MI355X': every listed name must be a collected gpu case."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import conftest
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests"), "-m", "gpu", "--collect-only", "-q"], cwd=REPO,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    funcs = {re.split(r"[\[ ]", ln.split("::")[-1])[0] for ln in r.stdout.splitlines() if "::" in ln}
+    assert len(funcs) > 50, len(funcs)          # 61 distinct gpu test functions (183 parametrised cases) at round 6
+    for name, group in (("_ON_HARDWARE_R1", conftest._ON_HARDWARE_R1), ("_ON_HARDWARE_R2", conftest._ON_HARDWARE_R2),
+                        ("_GOLDEN_MODEL_CASES", conftest._GOLDEN_MODEL_CASES)):
+        missing = sorted(set(group) - funcs)
+        assert not missing, f"tests/conftest.py {name} lists cases that no longer exist: {missing}"
+    for f in conftest._F_ROW_FILES:
+        assert os.path.exists(os.path.join(REPO, "tests", f)), f

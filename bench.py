@@ -15,8 +15,11 @@ between two barrier + synchronize brackets.
 Rank 0 prints ONE JSON line; it also carries
   roofline      : the dominant kernel (the 768 -> 3072 SiLU bf16 MFMA GEMM of the audio MLP), achieved algorithmic TFLOP/s
                   from its average launch duration measured with HIP events recorded inside the library on the launch
-                  stream, vs the 2.5 PFLOP/s dense bf16 MFMA peak; `traffic` = HBM / fabric bytes of one launch from the
-                  committed TCC-counter measurement named in `traffic_source` (rocprofv3 cannot run inside this process);
+                  stream, vs the 2.5 PFLOP/s dense bf16 MFMA peak; `traffic` = HBM / fabric bytes of one launch of that kernel from
+                  the TCC counters, collected by this run itself AFTER the timed region (N = 1, rank 0: tools/pmc_hbm.sh in
+                  child processes - separate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` passes over the same
+                  launch, calibrated on a stream of known size as MI355X_MICROARCH.md prescribes; --no-live-traffic or
+                  CACO_BENCH_LIVE_TRAFFIC=0 turns it off), else from the committed measurement named in `traffic_source`;
   stages        : the same per-launch-group timing for every stage (mel: HBM GB/s vs 8 TB/s);
   extra_configs : BASELINE configs[1] (audio tower only, batch 256) and configs[4] (AudioMAE stage-1 forward, batch 256),
                   measured in this run outside the timed region;
@@ -93,6 +96,48 @@ def _make_inputs(batch, rank, device):
     wav = np.concatenate([base * g for g in gains], 0)[:batch]
     ids, mask = synth.make_captions(batch, TEXT_LEN, 50265, start=batch * rank)
     return (torch.from_numpy(wav).to(device), torch.from_numpy(ids).to(device), torch.from_numpy(mask).to(device))
+
+
+def _measure_traffic_live(timeout_s: float = 300.0, tag: str = "bench_live_hbm"):
+    """HBM / fabric bytes of ONE fc1 launch from the TCC counters, measured by child processes of this run: tools/pmc_hbm.sh =
+    four `rocprofv3 --kernel-trace --pmc <one counter>` passes (FETCH_SIZE and WRITE_SIZE cannot share a pass; kernel-trace only, no
+    other tracing domain) - two over a streaming probe of known size (the calibration MI355X_MICROARCH.md asks for: on gfx950
+    FETCH_SIZE reports half of a wide coalesced read, WRITE_SIZE is uncalibrated) and two over tools/gemm_bench.py --only fc1, the
+    same kernel, shape, tile order and library as the step's fc1 launch.  rocprofv3 serialises the dispatches it counts, so the
+    figure is per launch.  Returns (record | None, reason): never raises, bounded by `timeout_s`, kills the whole process group
+    on a timeout.  Not inside the timed region; this process idles on a synchronised device while the children run."""
+    import shutil
+    import signal
+    import subprocess
+    if os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None, "this process itself runs under rocprofv3 (nested counter collection is not attempted)"
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        return None, "rocprofv3 not found"
+    out_dir = os.path.join(REPO, "gpurun_out", tag)
+    rec_path = os.path.join(out_dir, "hbm_traffic.json")
+    try:
+        if os.path.exists(rec_path):
+            os.remove(rec_path)
+        env = dict(os.environ, PATH=os.pathsep.join([os.environ.get("PATH", ""), os.path.dirname(sys.executable), "/opt/rocm/bin"]))
+        env.pop("CACO_BENCH_DRYRUN", None)
+        t0 = time.perf_counter()
+        proc = subprocess.Popen(["bash", os.path.join(REPO, "tools", "pmc_hbm.sh"), tag, "fc1", "256"], cwd=REPO, env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+        try:
+            log, _ = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            return None, f"tools/pmc_hbm.sh did not finish within {timeout_s:.0f} s (killed)"
+        if not os.path.exists(rec_path):
+            return None, f"tools/pmc_hbm.sh left no record (exit {proc.returncode}): {(log or '').strip().splitlines()[-1:]}"
+        rec = json.load(open(rec_path))
+        if not (rec.get("hbm_bytes", 0) > 0 and rec.get("dispatches", 0) >= 1):
+            return None, f"counter record unusable: {rec}"
+        rec["collect_s"] = round(time.perf_counter() - t0, 1)
+        return rec, "measured by this run"
+    except Exception as e:          # a side measurement: the bench line must survive anything here
+        return None, f"live counter pass failed: {e!r}"
 
 
 def _cpu_model():
@@ -303,6 +348,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not collect the fc1 launch's TCC counters in child rocprofv3 passes after the timed region")
     ap.add_argument("--audio-streams", type=int, default=1, help="streams the clip batch is split over (1 = one audio stream; the text tower always runs on its own)")
     args = ap.parse_args()
 
@@ -404,19 +450,32 @@ def main():
             dom = stages.get("audio.gemm_fc1")
             # HBM bytes of one fc1 launch: a committed TCC-counter measurement (tools/pmc_hbm.sh), quoted ONLY when it was taken
             # with the tile order this run uses (its "w_ngroup" field; a file without the field is of unknown order and never quoted).  Anything else would pair this run's time with another schedule's bytes.
-            traffic, traffic_source = None, None
+            traffic, traffic_source, traffic_rec = None, None, None
+            live_reason = "off (--no-live-traffic / CACO_BENCH_LIVE_TRAFFIC=0)"
+            if world == 1 and not args.no_live_traffic and os.environ.get("CACO_BENCH_LIVE_TRAFFIC", "1") not in ("", "0"):
+                torch.cuda.synchronize()
+                traffic_rec, live_reason = _measure_traffic_live()
             try:
                 import glob
                 ngroup_now = int(lib.caco_get_switch(b"CACO_W_NGROUP"))
-                for cand in sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True):
+                if traffic_rec is not None and int(traffic_rec.get("w_ngroup", -99)) == ngroup_now:
+                    traffic = int(traffic_rec["hbm_bytes"])
+                    traffic_source = (f"measured by this run after the timed region ({traffic_rec['collect_s']} s): tools/pmc_hbm.sh, separate rocprofv3 "
+                                      f"--kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes over {traffic_rec['dispatches']} fc1 launches of this library with "
+                                      f"the tile order in force (CACO_W_NGROUP = {ngroup_now}), calibrated on a stream of known size "
+                                      f"({traffic_rec['bytes_per_fetch_unit']:.0f} B per FETCH_SIZE unit, {traffic_rec['bytes_per_write_unit']:.0f} B per WRITE_SIZE "
+                                      f"unit); read {traffic_rec['hbm_read_bytes'] / 1e9:.3f} GB + write {traffic_rec['hbm_write_bytes'] / 1e9:.3f} GB per launch")
+                for cand in ([] if traffic is not None else sorted(glob.glob(os.path.join(REPO, "profiles", "*", "hbm_traffic.json")), reverse=True)):
                     rec = json.load(open(cand))
                     if "w_ngroup" in rec and int(rec["w_ngroup"]) == ngroup_now:      # no field = tile order unknown: never quoted
                         traffic = int(rec["hbm_bytes"])
                         traffic_source = (os.path.relpath(cand, REPO) + ": committed TCC FETCH_SIZE + WRITE_SIZE measurement of one fc1 "
-                                          "launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run")
+                                          f"launch (tools/pmc_hbm.sh, calibrated on a 1 GiB stream); NOT measured in this run (live pass: {live_reason})")
                         break
                 else:
-                    traffic_source = f"no committed hbm_traffic.json was measured with the tile order in force (CACO_W_NGROUP = {ngroup_now})"
+                    if traffic is None:
+                        traffic_source = (f"live counter pass: {live_reason}; no committed hbm_traffic.json was measured with the tile order in "
+                                          f"force (CACO_W_NGROUP = {ngroup_now})")
             except Exception:
                 traffic = None
             # algorithmic bytes of one fc1 launch: A [M,768] bf16 in + W [3072,768] bf16 in + out [M,3072] bf16

@@ -18,5 +18,6 @@ Cfg.default_text_config = lambda: replace(_t(), num_hidden_layers=1)
 import bench  # noqa: E402
 
 bench.B_PER_GPU = 2
-sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--no-extra-configs"]
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--profile-steps", "1", "--no-cpu-baseline", "--no-extra-configs",
+            "--no-live-traffic"]          # the counter pass spawns rocprofv3 children: hardware only (tests/test_bench_traffic.py covers its plumbing)
 bench.main()

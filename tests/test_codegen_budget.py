@@ -222,6 +222,37 @@ def _skew_kernel_checks(text, kernels, meta, name, fold):
     assert any(inn[lab] for lab in labels), "the data flow found no residual register in flight anywhere: the check checks nothing"
     for lab in labels:
         transfer(lab, inn[lab], True)
+    # hipcc pads nothing INSIDE an inline-assembly string and its hazard recogniser does not see the string as a memory instruction
+    # (cdna_hip_programming.md, inline assembly: "an "s" operand fresh from readfirstlane -> a buffer_* inside reading it as
+    # descriptor, soffset or base" needs its wait states by hand): a vector instruction writing one of the descriptor's scalar
+    # registers must lie at least 5 wait states ahead of every residual load, on the straight-line code before it (labels crossed:
+    # the conservative reading).  Today the descriptor is built from scalar loads / s_mov long before the first event.
+    flat_lines = [l.split(";")[0].strip() for l in lines[start + 1:end]]
+    flat_lines = [l for l in flat_lines if l and not l.startswith(".") or re.match(r"\.LBB\d+_\d+:", l or "")]
+    n_checked = 0
+    for at, l in enumerate(flat_lines):
+        if not (l.startswith("buffer_load_dwordx4") and " nt" in l and "lds" not in l):
+            continue
+        m = re.search(r"s\[(\d+):(\d+)\]", l)
+        desc = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        states, j = 0, at - 1
+        while j >= 0 and states < 5:
+            t = flat_lines[j]
+            j -= 1
+            if t.endswith(":"):
+                continue
+            op = t.split()[0]
+            if op == "s_nop":
+                states += int(t.split()[1]) + 1
+                continue
+            if op.startswith(("v_readfirstlane", "v_readlane")) or (op.startswith("v_cmp") and t.split()[1].startswith("s")):
+                dst = t.split()[1].rstrip(",")
+                mm = re.fullmatch(r"s\[(\d+):(\d+)\]", dst)
+                written = set(range(int(mm.group(1)), int(mm.group(2)) + 1)) if mm else ({int(dst[1:])} if re.fullmatch(r"s\d+", dst) else set())
+                assert not (written & desc), f"`{t}` writes a descriptor register {states} wait states ahead of `{l}` (needs 5)"
+            states += 1
+        n_checked += 1
+    assert n_checked == 36
 
 
 def test_attention_resources(attention_asm):

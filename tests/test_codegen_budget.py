@@ -270,7 +270,7 @@ def test_attention_lean_variant_budget(tmp_path_factory):
     """Variant build `attn_lean` (-DATTN_LEAN; the default attention kernels stay the round-2 instruction streams): no attention
     kernel spills, the two-block kernel's output epilogue carries no v_perm / v_alignbit around its bf16 conversions and is at
     least 120 instructions shorter per wave, and its tile loop is unchanged in matrix work."""
-    base_k, base_m = _kernels(_assembly("attention.hip", tmp_path_factory))
+    base_k, base_m = _kernels(_assembly("attention.hip", tmp_path_factory, ["-UATTN_LEAN"]))      # explicit: stays the other arm after a flip
     lean_k, lean_m = _kernels(_assembly("attention.hip", tmp_path_factory, ["-DATTN_LEAN"]))
     assert lean_m and all(m["scratch"] == 0 for m in lean_m.values()), {k[-40:]: m for k, m in lean_m.items() if m["scratch"]}
     audio = _find(lean_m, "attention_kernelILi96ELb0ELi4ELi2ELb0E")

@@ -94,6 +94,17 @@ def skew_sim():
     return _variant_sim("skew", ["-DW8_F32_SKEW"])
 
 
+@pytest.fixture(scope="module")
+def noskew_sim(sim):
+    """The other arm of every skew comparison: the build WITHOUT -DW8_F32_SKEW.  That is the suite's own library as long as the
+    product build does not define it (cacophony_amd/build.py EXTRA_FLAGS); after a flip it is an explicit -U build, so that the
+    cases below keep comparing the skewed kernel with gemm_bf16_w8 instead of with itself."""
+    from cacophony_amd.build import EXTRA_FLAGS
+    if "-DW8_F32_SKEW" not in EXTRA_FLAGS.get("gemm_w8.hip", []):
+        return sim
+    return _variant_sim("noskew", ["-UW8_F32_SKEW"])
+
+
 def _skew_case(lib, M, N, K, seed, inplace=True, guard=3):
     a = _rand((M, K), seed).bfloat16()
     w = _rand((N, K), seed + 1, 1.0 / math.sqrt(K)).bfloat16()
@@ -121,7 +132,7 @@ def _skew_case(lib, M, N, K, seed, inplace=True, guard=3):
     (2304, 512, 3072, True),       # fc2 K: nk = 48, D = 6; two n-tiles: 8 teams, 9 panels (one team walks two)
     (2304, 1024, 576, True),       # the smallest K the kernel takes (nk = 9); four n-tiles: 4 teams
 ])
-def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
+def test_gemm_skewed_row_blocks(skew_sim, noskew_sim, M, N, K, inplace):
     """Variant build `skew` (-DW8_F32_SKEW, csrc/gemm_w8_skew.inc): the fp32 + bias + residual GEMM whose epilogue runs under its
     own K-loop.  Against torch fp32 at fp32 rounding (sum order differs from the other kernels: bias first, K-tiles rotated per
     row block), with guard rows around the output, in place and with a separate residual; and the DEFAULT build on the same
@@ -136,20 +147,20 @@ def test_gemm_skewed_row_blocks(skew_sim, sim, M, N, K, inplace):
     d32 = ((out - ref).abs() / (ref.abs() + 1.0)).max().item()      # two fp32 roundings apart: up to the sum of both errors
     print(f"[skew] M {M} N {N} K {K}: vs float64 {err:.2e} (torch fp32 {err32:.2e}), vs torch fp32 {d32:.2e}")
     assert d32 <= (3.5e-6 if K <= 1024 else 7e-6)
-    base, _, _ = _skew_case(sim, M, N, K, 40, inplace=inplace)
+    base, _, _ = _skew_case(noskew_sim, M, N, K, 40, inplace=inplace)
     assert not torch.equal(base, out), "identical bits: the skewed kernel did not run"
     assert (base - out).abs().max().item() < 1e-4
 
 
-def test_gemm_skewed_falls_back_where_it_does_not_apply(skew_sim, sim):
+def test_gemm_skewed_falls_back_where_it_does_not_apply(skew_sim, noskew_sim):
     """Launches that do not fill the chip, K < 576 and gathered / absent residuals stay on gemm_bf16_w8: bitwise the default's."""
     for M, N, K in ((1024, 768, 768), (2048, 768, 512), (2048, 256, 768)):
         a, _, _ = _skew_case(skew_sim, M, N, K, 50)
-        b, _, _ = _skew_case(sim, M, N, K, 50)
+        b, _, _ = _skew_case(noskew_sim, M, N, K, 50)
         assert torch.equal(a, b), (M, N, K)
 
 
-def test_gemm_skewed_linear_panel_list(sim):
+def test_gemm_skewed_linear_panel_list(noskew_sim):
     """The linear form of the same kernel (-DW8_SKEW_LINEAR, variant `skew_lin`: first-period blocks idle, a tail period at the
     end) - the other arm of the A/B against the circular panel list of `skew`."""
     lin = _variant_sim("skew_lin", ["-DW8_F32_SKEW", "-DW8_SKEW_LINEAR"])
@@ -157,7 +168,7 @@ def test_gemm_skewed_linear_panel_list(sim):
         out, ref, ref64 = _skew_case(lin, M, N, K, 40, inplace=inplace)
         err = ((out.double() - ref64).abs() / (ref64.abs() + 1.0)).max().item()
         assert err <= (3e-6 if K <= 1024 else 7e-6), (M, N, K, err)
-        base, _, _ = _skew_case(sim, M, N, K, 40, inplace=inplace)
+        base, _, _ = _skew_case(noskew_sim, M, N, K, 40, inplace=inplace)
         assert not torch.equal(base, out)
 
 
@@ -182,7 +193,7 @@ def test_gemm_skewed_other_team_geometries(skew_sim):
 
 
 @pytest.mark.parametrize("ln_fold", [0, 1])
-def test_audio_layer_with_skewed_gemms_matches_the_default_build(skew_sim, sim, tiny_state, ln_fold):
+def test_audio_layer_with_skewed_gemms_matches_the_default_build(skew_sim, noskew_sim, tiny_state, ln_fold):
     """One full-width audio layer at batch 8 with the persistent GEMM forced on (CACO_W8_MIN_TILES = 1): out-proj (K = 768, D = 1)
     and fc2 (K = 3072, D = 6) run on the skewed kernel inside the model's launch sequence - in-place residual stream, the real
     strides.  The embeddings must equal the default build's to fp32 rounding, and differ from them in bits (else it fell back).
@@ -194,7 +205,7 @@ def test_audio_layer_with_skewed_gemms_matches_the_default_build(skew_sim, sim, 
     state = {k: v for k, v in tiny_state.items() if ".layers.1." not in k and "layers_1" not in k}
     wav = torch.from_numpy(synth.make_waveforms(8, start=40))
     embs = []
-    for lib in (sim, skew_sim):
+    for lib in (noskew_sim, skew_sim):
         prev = lib.caco_get_switch(b"CACO_W8_MIN_TILES")
         assert lib.caco_set_switch(b"CACO_W8_MIN_TILES", 1) == 0
         try:

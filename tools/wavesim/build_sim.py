@@ -102,7 +102,8 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
 
     # A variant's -D macros usually touch one translation unit: a unit whose source (and the csrc headers / .inc pieces, which any
     # unit may include) never names one of them compiles to the same object as in the untagged build, so that object is shared.
-    macros = [re.sub(r"^-D", "", d).split("=")[0] for d in defines if d.startswith("-D")]
+    # (-U<macro> counts as well: the "base" arm of a flipped variant undoes the product build's own -D, which comes first on the command line)
+    macros = [re.sub(r"^-[DU]", "", d).split("=")[0] for d in defines if d.startswith(("-D", "-U"))]
     san_tag = (".asan" if asan else "") + (".tsan" if tsan else "") + (".ubsan" if ubsan else "")
 
     def closure_text(path, seen=None):
@@ -140,8 +141,9 @@ def build(force: bool = False, asan: bool = False, extra=(), lib: str = LIB, ver
         else:
             gen = path
         san = ["-fsanitize=thread"] if (tsan and base.endswith(".hip")) else []
-        use_flags = [f for f in flags if f not in defines] if obj_tag != tag else flags
-        cmd = [CXX, *use_flags, *[f for f in product_extra.get(base, []) if f.startswith("-D")], *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
+        use_defines = list(defines) if obj_tag == tag else []
+        use_flags = [f for f in flags if f not in defines]
+        cmd = [CXX, *use_flags, *[f for f in product_extra.get(base, []) if f.startswith("-D")], *use_defines, *san, "-I", SHIM, "-I", HERE, "-I", CSRC, "-I", INCLUDE, "-c", gen, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"{base}:\n{r.stdout}\n{r.stderr}")

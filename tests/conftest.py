@@ -126,7 +126,7 @@ def _gpu_cases_run_on_the_product_library(request):
     yield
     if request.node.get_closest_marker("gpu") is None or os.environ.get("CACO_GPU_ON_SIM") == "1":
         return
-    if os.environ.get("CACO_ALLOW_VARIANT_LIB") == "1":          # tools/ab_bench.sh style runs of a variant build
+    if os.environ.get("CACO_ALLOW_VARIANT_LIB") == "1":          # a variant library under the suite on purpose (tools/gpu_session.sh variants / bisect)
         return
     from cacophony_amd import _lib
     product = os.path.realpath(os.path.join(REPO, "cacophony_amd", "libcaco_hip.so"))

@@ -11,7 +11,7 @@ Per-stage times come from each library's own HIP-event recorder.  Verdict as in 
 default in EVERY repetition by more than --margin ms, LOSE when it loses in every repetition by that margin, else inside the margin.
 Each variant's similarity matrix is compared with the default's.
 
-Replaces tools/ab_bench.sh (one bench.py process per variant and repetition: ~35 s each, not interleaved).  The product never
+(Round 1-3 ran one bench.py process per variant and repetition: ~35 s each, not interleaved.)  The product never
 loads a variant library; this tool is the only place several are in one process.
 """
 from __future__ import annotations

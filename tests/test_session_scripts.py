@@ -13,7 +13,7 @@ def test_every_part_of_the_gpu_session_dry_runs_clean():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "PASS" in r.stdout.splitlines()[-1], tail
     assert "all scripts and flags exist" in r.stdout, tail
-    for part in ("truth", "ab", "variants", "pmc", "bisect"):
+    for part in ("quick", "truth", "ab", "variants", "pmc", "bisect"):
         assert f"== dry run: gpu_session.sh {part}" in r.stdout
     # the records the later steps depend on were produced by the scripts' own plumbing (fabricated counters, real csv readers)
     for name in ("pytest_gpu.txt", "smoke.txt", "bench.json", "kernel_stats_default.csv", "hbm_traffic.json", "pmc_fc1_tcc1.csv",

@@ -17,6 +17,17 @@ OUT=${OUT:-gpurun_out/r6_v0}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
+# 0. quick (never part of `all`): the shortest hardware record of the default build - pytest -m gpu (default path), smoke, bench with its
+#    own counter pass; no rocprofv3 kernel stats, no experimental cases.  For a pool that opens with little session time left.
+if [ "$PART" = quick ]; then
+echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ) (quick)" > "$OUT/session.txt"
+(timeout 900 python -m pytest tests -m gpu -q -rfE --tb=short 2>&1 | tail -120) > "$OUT/pytest_gpu.txt"
+tail -3 "$OUT/pytest_gpu.txt"
+(timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > "$OUT/smoke.txt"
+cat "$OUT/smoke.txt"
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+head -c 1500 "$OUT/bench.json"; echo
+fi
 if want truth; then
 echo "HEAD $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > "$OUT/session.txt"
 (timeout 1200 python -m pytest tests -m gpu -q -rfE --tb=short 2>&1 | tail -120) > "$OUT/pytest_gpu.txt"                  # the product: default path only

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Dry run of tools/gpu_session.sh WITHOUT a GPU (round 6): catches script errors before they cost GPU minutes.
-#   bash tools/session_dryrun.sh [parts...]        default: truth ab variants pmc bisect
+#   bash tools/session_dryrun.sh [parts...]        default: quick truth ab variants pmc bisect
 # How: `python`, `rocprofv3` and `timeout` are shadowed by logging fakes (a temp directory first on PATH); the fake rocprofv3
 # fabricates the csv files the scripts look for and then runs its command through the fake python.  Afterwards every logged python
 # command line is checked: the script exists, and every --flag it was given is one the script's own --help lists.
 # Nothing here measures anything; the only outputs are the log and a PASS / FAIL line (exit code 1 on FAIL).
 set -u
 cd "$(dirname "$0")/.."
-PARTS=${*:-truth ab variants pmc bisect}
+PARTS=${*:-quick truth ab variants pmc bisect}
 T=$(mktemp -d); LOG=$T/commands.log; : > "$LOG"
 # the scripts write under gpurun_out/ of the tree they run in: run them in a throw-away copy, so that no fabricated record
 # (an hbm_traffic.json made of the fake counters, say) can ever sit next to real ones

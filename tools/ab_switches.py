@@ -148,11 +148,14 @@ def main():
             verdict = "KEEP-OFF (inside the margin)"
         rows.append({"config": name, "switches": cfg, "ms_mean": round(float(tms.mean()), 3), "ms_min": round(float(tms.min()), 3),
                      "ms_max": round(float(tms.max()), 3), "delta_mean": round(float(d.mean()), 3), "delta_min": round(float(d.min()), 3),
-                     "delta_max": round(float(d.max()), 3), "verdict": verdict, **checks[name], "stages_ms": stages[name]})
-    print(f"{'config':<18} {'ms mean':>8} {'min':>8} {'max':>8} {'d mean':>8} {'d min':>8} {'d max':>8}  {'|dsim|':>8}  verdict")
+                     "delta_max": round(float(d.max()), 3), "verdict": verdict, **checks[name], "stages_ms": stages[name],
+                     # a fusion that removes one small launch (pos_fuse: <= 0.14 ms, pool_fuse: <= 0.10 ms) cannot clear the step margin by
+                     # construction: its evidence is the single-stream stage sum (one pass, HIP events), reported next to the verdict
+                     "delta_stage_sum": round(stages[name]["sum_all_stages"] - stages["default"]["sum_all_stages"], 3)})
+    print(f"{'config':<18} {'ms mean':>8} {'min':>8} {'max':>8} {'d mean':>8} {'d min':>8} {'d max':>8} {'d stages':>9}  {'|dsim|':>8}  verdict")
     for r in rows:
         print(f"{r['config']:<18} {r['ms_mean']:8.3f} {r['ms_min']:8.3f} {r['ms_max']:8.3f} {r['delta_mean']:+8.3f} {r['delta_min']:+8.3f} "
-              f"{r['delta_max']:+8.3f}  {r['max_abs_diff_vs_default']:8.1e}  {r['verdict']}")
+              f"{r['delta_max']:+8.3f} {r['delta_stage_sum']:+9.3f}  {r['max_abs_diff_vs_default']:8.1e}  {r['verdict']}")
     print("\nper-stage ms of one single-stream pass (library HIP events):")
     keys = [k for k in STAGES if any(k in stages[n] for n, _ in configs)] + ["sum_all_stages"]
     print(f"{'config':<18} " + " ".join(f"{(k[0] + '.' + k.split('.')[-1].replace('gemm_', ''))[:9]:>9}" for k in keys))
